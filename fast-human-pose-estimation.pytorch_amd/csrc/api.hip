@@ -1,0 +1,271 @@
+// C-ABI entry points (include/fpd_amd.h): argument validation, backend dispatch, execution plan,
+// hipGraph capture/replay, HIP-event timing helpers.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
+int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
+int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
+int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st);
+int fpd_adam_launch(const fpd_adam_t& a, hipStream_t st);
+int fpd_weight_prep_launch(const fpd_wprep_entry_t* table, int n, int64_t max_elems, int dtype, hipStream_t st);
+int fpd_bn_update_running_launch(const fpd_bnupd_entry_t* table, int n, hipStream_t st);
+int fpd_cast_launch(const void* src, void* dst, int64_t n, int sd, int dd, hipStream_t st);
+int fpd_nchw_to_nhwc_launch(const float* src, void* dst, int N, int C, int H, int W, int dtype, hipStream_t st);
+int fpd_nhwc_to_nchw_launch(const void* src, float* dst, int N, int C, int H, int W, int dtype, hipStream_t st);
+
+int g_fpd_backend = FPD_BACKEND_MFMA;
+static thread_local char g_err[512] = "";
+
+int fpd_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fpd_fail(-100 - (int)e, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static int validate_conv_dims(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int P, int Q) {
+    FPD_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+                "conv: non-positive dimension");
+    FPD_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1,
+                "conv: output %dx%d inconsistent with input %dx%d k=%dx%d stride=%d pad=%d", P, Q, H, W, R, S, stride, pad);
+    FPD_REQUIRE((int64_t)N * H * W * C < (1ll << 31) && (int64_t)N * P * Q * K < (1ll << 31), "conv: tensor too large for 32-bit indexing");
+    return 0;
+}
+
+extern "C" {
+
+const char* fpd_last_error(void) { return g_err; }
+int fpd_abi_version(void) { return 1; }
+int fpd_set_backend(int32_t backend) {
+    const int prev = g_fpd_backend;
+    if (backend == FPD_BACKEND_MFMA || backend == FPD_BACKEND_NAIVE) g_fpd_backend = backend;
+    return prev;
+}
+
+int fpd_abi_sizeof(const char* n) {
+#define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
+    SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t);
+#undef SZ
+    return -1;
+}
+
+int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->x && a->w && a->y, "conv: null pointer");
+    int rc = validate_conv_dims(a->N, a->H, a->W, a->C, a->K, a->R, a->S, a->stride, a->pad, a->P, a->Q);
+    if (rc) return rc;
+    FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "conv: bad dtype %d", a->dtype);
+    FPD_REQUIRE(a->bn.mode == FPD_BN_NONE || (a->bn.gamma && a->bn.beta), "conv: BN prologue without gamma/beta");
+    FPD_REQUIRE(a->bn.mode != FPD_BN_TRAIN || a->bn.stats, "conv: train-mode BN without statistics");
+    FPD_REQUIRE(a->bn.mode != FPD_BN_EVAL || (a->bn.running_mean && a->bn.running_var), "conv: eval-mode BN without running stats");
+    FPD_REQUIRE(a->epi == FPD_EPI_PLAIN || (a->epi_x && a->epi_stats && a->epi_bn.mode == FPD_BN_TRAIN && a->epi_bn.stats),
+                "conv: BNRELU_BWD epilogue needs epi_x, epi_stats and a train-mode epi_bn");
+    hipStream_t st = (hipStream_t)stream;
+    rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_mfma_launch(*a, st);
+    if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
+    return rc ? rc : check_launch();
+}
+
+int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->x && a->dy && a->dw, "wgrad: null pointer");
+    int rc = validate_conv_dims(a->N, a->H, a->W, a->C, a->K, a->R, a->S, a->stride, a->pad, a->P, a->Q);
+    if (rc) return rc;
+    FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "wgrad: bad dtype %d", a->dtype);
+    hipStream_t st = (hipStream_t)stream;
+    rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_mfma_launch(*a, st);
+    if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
+    return rc ? rc : check_launch();
+}
+
+int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->x && a->w && a->bias && a->y, "stem: null pointer");
+    FPD_REQUIRE(a->P == (a->H + 6 - 7) / 2 + 1 && a->Q == (a->W + 6 - 7) / 2 + 1, "stem: bad output size");
+    int rc = fpd_stem_forward_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->x && a->dy && a->dw, "stem wgrad: null pointer");
+    int rc = fpd_stem_wgrad_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->y, "elementwise: null pointer");
+    int rc = fpd_elementwise_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_loss(const fpd_loss_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->teacher && a->target && a->weight && a->losses, "loss: null pointer");
+    int rc = fpd_loss_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_adam(const fpd_adam_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->param && a->grad && a->m && a->v && a->n >= 0, "adam: null pointer");
+    int rc = fpd_adam_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_weight_prep(const fpd_wprep_entry_t* t, int32_t n, int64_t max_elems, int32_t dtype, fpd_stream_t stream) {
+    int rc = fpd_weight_prep_launch(t, n, max_elems, dtype, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_bn_update_running(const fpd_bnupd_entry_t* t, int32_t n, fpd_stream_t stream) {
+    int rc = fpd_bn_update_running_launch(t, n, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, fpd_stream_t stream) {
+    int rc = fpd_cast_launch(src, dst, n, sd, dd, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_nchw_to_nhwc(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype, fpd_stream_t stream) {
+    int rc = fpd_nchw_to_nhwc_launch(src, dst, N, C, H, W, dtype, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype, fpd_stream_t stream) {
+    int rc = fpd_nhwc_to_nchw_launch(src, dst, N, C, H, W, dtype, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// execution plan
+// ------------------------------------------------------------------------------------------
+struct fpd_op {
+    int32_t type;
+    union {
+        fpd_conv_t conv; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_memset_t mset; fpd_table_t table;
+    } u;
+};
+struct fpd_plan {
+    std::vector<fpd_op> ops;
+    std::vector<hipGraphExec_t> graphs;
+    std::vector<hipGraph_t> graph_defs;
+};
+
+fpd_plan* fpd_plan_create(void) { return new fpd_plan(); }
+void fpd_plan_destroy(fpd_plan* p) {
+    if (!p) return;
+    for (auto g : p->graphs) (void)hipGraphExecDestroy(g);
+    for (auto g : p->graph_defs) (void)hipGraphDestroy(g);
+    delete p;
+}
+int fpd_plan_size(const fpd_plan* p) { return p ? (int)p->ops.size() : -1; }
+
+int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
+    FPD_REQUIRE(p && args, "plan_add: null");
+    fpd_op o;
+    memset(&o, 0, sizeof(o));
+    o.type = op;
+    size_t want = 0;
+    switch (op) {
+        case FPD_OP_CONV: want = sizeof(fpd_conv_t); break;
+        case FPD_OP_WGRAD: want = sizeof(fpd_wgrad_t); break;
+        case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: want = sizeof(fpd_stem_t); break;
+        case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
+        case FPD_OP_LOSS: want = sizeof(fpd_loss_t); break;
+        case FPD_OP_ADAM: want = sizeof(fpd_adam_t); break;
+        case FPD_OP_MEMSET: want = sizeof(fpd_memset_t); break;
+        case FPD_OP_WPREP: case FPD_OP_BNUPD: want = sizeof(fpd_table_t); break;
+        default: return fpd_fail(-2, "plan_add: unknown op %d", op);
+    }
+    FPD_REQUIRE((size_t)bytes == want, "plan_add: op %d expects %zu bytes of args, got %lld", op, want, (long long)bytes);
+    memcpy(&o.u, args, want);
+    p->ops.push_back(o);
+    return (int)p->ops.size() - 1;
+}
+
+static int run_op(const fpd_op& o, fpd_stream_t s) {
+    switch (o.type) {
+        case FPD_OP_CONV: return fpd_conv_forward(&o.u.conv, s);
+        case FPD_OP_WGRAD: return fpd_conv_wgrad(&o.u.wgrad, s);
+        case FPD_OP_STEM_FWD: return fpd_stem_forward(&o.u.stem, s);
+        case FPD_OP_STEM_WGRAD: return fpd_stem_wgrad(&o.u.stem, s);
+        case FPD_OP_EW: return fpd_elementwise(&o.u.ew, s);
+        case FPD_OP_LOSS: return fpd_loss(&o.u.loss, s);
+        case FPD_OP_ADAM: return fpd_adam(&o.u.adam, s);
+        case FPD_OP_MEMSET: {
+            FPD_CHECK_HIP(hipMemsetAsync(o.u.mset.ptr, 0, (size_t)o.u.mset.bytes, (hipStream_t)s));
+            return 0;
+        }
+        case FPD_OP_WPREP:
+            return fpd_weight_prep((const fpd_wprep_entry_t*)o.u.table.table, o.u.table.n, o.u.table.max_elems, o.u.table.dtype, s);
+        case FPD_OP_BNUPD: return fpd_bn_update_running((const fpd_bnupd_entry_t*)o.u.table.table, o.u.table.n, s);
+    }
+    return fpd_fail(-2, "run_op: unknown op %d", o.type);
+}
+
+int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
+    FPD_REQUIRE(p && begin >= 0 && end <= (int)p->ops.size() && begin <= end, "plan_run: bad range [%d,%d)", begin, end);
+    for (int i = begin; i < end; ++i) {
+        int rc = run_op(p->ops[i], stream);
+        if (rc) {
+            char tmp[400];
+            snprintf(tmp, sizeof(tmp), "%s", g_err);
+            return fpd_fail(rc, "plan op %d (type %d): %s", i, p->ops[i].type, tmp);
+        }
+    }
+    return 0;
+}
+
+int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
+    FPD_REQUIRE(p, "plan_capture: null");
+    hipStream_t st = (hipStream_t)stream;
+    FPD_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = fpd_plan_run(p, begin, end, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    hipGraphExec_t ge = nullptr;
+    FPD_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    p->graph_defs.push_back(g);
+    p->graphs.push_back(ge);
+    return (int)p->graphs.size() - 1;
+}
+
+int fpd_plan_replay(fpd_plan* p, int32_t gid, fpd_stream_t stream) {
+    FPD_REQUIRE(p && gid >= 0 && gid < (int)p->graphs.size(), "plan_replay: bad graph id %d", gid);
+    FPD_CHECK_HIP(hipGraphLaunch(p->graphs[gid], (hipStream_t)stream));
+    return 0;
+}
+
+void* fpd_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+int fpd_event_record(void* ev, fpd_stream_t stream) {
+    FPD_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+float fpd_event_elapsed_ms(void* start, void* stop) {
+    float ms = -1.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
+}
+void fpd_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+}  // extern "C"

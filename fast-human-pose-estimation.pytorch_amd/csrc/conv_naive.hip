@@ -1,0 +1,117 @@
+// Direct (one thread per output) HIP convolution kernels with the same fused prologue/epilogue contract
+// as conv_mfma.hip.  They serve as the on-device cross-check of the MFMA kernels, and as the HIP path for
+// shapes the MFMA tiling does not cover (channel counts that are not a multiple of 16, e.g. J = 17).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
+    __shared__ float s_scale[FPD_MAXC], s_shift[FPD_MAXC];
+    __shared__ float s_epi[4][FPD_MAXC];
+    const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, S = a.S, P = a.P, Q = a.Q;
+    const int M = a.N * P * Q;
+    bn_fill(a.bn, C, (double)a.N * H * W, s_scale, s_shift);
+    if (a.epi == FPD_EPI_BNRELU_BWD) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x)
+            bn_coef(a.epi_bn, k, K, (double)M, s_epi[0][k], s_epi[1][k], s_epi[2][k], s_epi[3][k]);
+    }
+    __syncthreads();
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* w = reinterpret_cast<const T*>(a.w);
+    const T* res = reinterpret_cast<const T*>(a.residual);
+    const T* ex = reinterpret_cast<const T*>(a.epi_x);
+    T* y = reinterpret_cast<T*>(a.y);
+    const size_t total = (size_t)M * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / K), k = (int)(idx - (size_t)m * K);
+        const int n = m / (P * Q), rem = m - n * (P * Q);
+        const int p = rem / Q, q = rem - p * Q;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int ih = p * a.stride - a.pad + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int s = 0; s < S; ++s) {
+                const int iw = q * a.stride - a.pad + s;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const T* xp = x + (size_t)((n * H + ih) * W + iw) * C;
+                const T* wp = w + (size_t)((k * R + r) * S + s) * C;
+                for (int c = 0; c < C; ++c) {
+                    float xv = DT<T>::ld(xp + c);
+                    if (a.bn.mode != FPD_BN_NONE) xv = DT<T>::rnd(bn_act(xv, s_scale[c], s_shift[c], a.bn.relu));
+                    acc = fmaf(xv, DT<T>::ld(wp + c), acc);
+                }
+            }
+        }
+        float v = acc + (a.bias ? a.bias[k] : 0.f);
+        if (res) v += DT<T>::ld(res + idx);
+        if (a.epi == FPD_EPI_BNRELU_BWD) {
+            const float xv = DT<T>::ld(ex + idx);
+            const float z = fmaf(xv, s_epi[0][k], s_epi[1][k]);
+            v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
+            const float vr = DT<T>::rnd(v);
+            atomicAdd(a.epi_stats + k, (double)vr);
+            atomicAdd(a.epi_stats + K + k, (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k])));
+        } else if (a.out_stats) {
+            const float vr = DT<T>::rnd(v);
+            atomicAdd(a.out_stats + k, (double)vr);
+            atomicAdd(a.out_stats + K + k, (double)(vr * vr));
+        }
+        DT<T>::st(y + idx, v);
+    }
+}
+
+// one thread per weight element, serial loop over all pixels (deterministic; debugging / odd shapes)
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
+    __shared__ float s_scale[FPD_MAXC], s_shift[FPD_MAXC];
+    const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, S = a.S, P = a.P, Q = a.Q;
+    const int M = a.N * P * Q;
+    bn_fill(a.bn, C, (double)a.N * H * W, s_scale, s_shift);
+    __syncthreads();
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    const int total = K * R * S * C;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % C, s = (idx / C) % S, r = (idx / (C * S)) % R, k = idx / (C * S * R);
+    float acc = 0.f, bsum = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float g = DT<T>::ld(dy + (size_t)m * K + k);
+        bsum += g;
+        const int n = m / (P * Q), rem = m - n * (P * Q);
+        const int p = rem / Q, q = rem - p * Q;
+        const int ih = p * a.stride - a.pad + r, iw = q * a.stride - a.pad + s;
+        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+        float xv = DT<T>::ld(x + (size_t)((n * H + ih) * W + iw) * C + c);
+        if (a.bn.mode != FPD_BN_NONE) xv = DT<T>::rnd(bn_act(xv, s_scale[c], s_shift[c], a.bn.relu));
+        acc = fmaf(g, xv, acc);
+    }
+    a.dw[idx] += acc;
+    if (a.dbias && c == 0 && r == 0 && s == 0) a.dbias[k] += bsum;
+}
+
+}  // namespace
+
+int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st) {
+    if (a.C > FPD_MAXC || a.K > FPD_MAXC) return fpd_fail(-3, "conv: channel count above %d", FPD_MAXC);
+    const size_t total = (size_t)a.N * a.P * a.Q * a.K;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+    if (a.dtype == FPD_BF16)
+        hipLaunchKernelGGL((conv_naive_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_naive_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+
+int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st) {
+    if (a.C > FPD_MAXC) return fpd_fail(-3, "wgrad: channel count above %d", FPD_MAXC);
+    const int total = a.K * a.R * a.S * a.C;
+    if (a.dtype == FPD_BF16)
+        hipLaunchKernelGGL((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+    return 0;
+}

@@ -1,0 +1,219 @@
+// HBM-bound NHWC kernels of the hourglass graph and its backward: BN+ReLU, 2x2 max-pool, nearest x2
+// up-add, their gradients, BatchNorm-backward apply.  16-byte vectors along C, one vector per thread per
+// step, grid-stride over pixels; producers of a tensor that feeds a train-mode BN accumulate its
+// per-channel {sum, sum^2} (fp32 in registers -> LDS -> one fp64 atomic per channel per block).
+// Replaces F.max_pool2d / nn.Upsample / nn.BatchNorm2d / nn.ReLU and their autograd in
+// /root/reference/lib/models/hourglass.py:80-92,172-177.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void ldv(const T* p, float* f) {
+    DT<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
+}
+template <typename T>
+__device__ __forceinline__ void stv(T* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = DT<T>::pack(f);
+}
+
+// One thread owns channel-vector `cv` (VEC channels) and walks pixels pl, pl+stride, ...
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
+    constexpr int VEC = DT<T>::VEC;
+    __shared__ float s_t0[FPD_MAXC], s_t1[FPD_MAXC], s_t2[FPD_MAXC], s_t3[FPD_MAXC];
+    __shared__ float s_sum[2][FPD_MAXC];
+    const int tid = threadIdx.x;
+    const int C = a.C, H = a.H, W = a.W, N = a.N;
+    const int VP = C / VEC;              // vectors per pixel
+    const int PB = 256 / VP;             // pixels per block step (VP <= 128 guaranteed by host)
+    const int cv = (tid % VP) * VEC;
+    const int pl = tid / VP;
+    const bool active = pl < PB;
+    constexpr bool HALF_OUT = (OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_MAXPOOL_BWD || OP == FPD_EW_SUMPOOL);
+    const int OH = HALF_OUT ? H / 2 : H, OW = HALF_OUT ? W / 2 : W;   // iteration space
+    const int npix = N * OH * OW;
+    constexpr bool STATS = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD);
+    constexpr bool BSTATS = (OP == FPD_EW_BNRELU_BWD_R);
+
+    // per-channel tables
+    if (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_BNRELU_BWD_R || OP == FPD_EW_BN_BWD_APPLY) {
+        const double cnt = (double)N * H * W;
+        for (int c = tid; c < C; c += 256) {
+            float sc, sh, mu, is;
+            bn_coef(a.bn, c, C, cnt, sc, sh, mu, is);
+            if (OP == FPD_EW_BN_BWD_APPLY) {
+                s_t0[c] = a.bn.gamma[c] * is;                 // gamma * invstd
+                s_t1[c] = (float)(a.bstats[c] / cnt);         // mean(dz)
+                s_t2[c] = (float)(a.bstats[C + c] / cnt);     // mean(dz * xhat)
+                s_t3[c] = mu;
+                s_sum[0][c] = is;
+                if (blockIdx.x == 0) {   // gradients of the BN affine parameters fall out of the two sums
+                    if (a.dgamma) a.dgamma[c] = (float)a.bstats[C + c];
+                    if (a.dbeta) a.dbeta[c] = (float)a.bstats[c];
+                }
+            } else {
+                s_t0[c] = sc; s_t1[c] = sh; s_t2[c] = mu; s_t3[c] = is;
+            }
+        }
+    }
+    if (STATS || BSTATS)
+        for (int c = tid; c < C; c += 256) { s_sum[0][c] = 0.f; s_sum[1][c] = 0.f; }
+    __syncthreads();
+
+    float acc1[VEC], acc2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
+
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* x2 = reinterpret_cast<const T*>(a.x2);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    const T* add = reinterpret_cast<const T*>(a.add);
+    T* y = reinterpret_cast<T*>(a.y);
+    const bool do_stats = STATS ? (a.out_stats != nullptr) : BSTATS;
+
+    if (active) {
+        for (int pix = blockIdx.x * PB + pl; pix < npix; pix += gridDim.x * PB) {
+            float o[VEC];
+            if (OP == FPD_EW_BNRELU_FWD) {
+                float v[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = bn_act(v[j], s_t0[cv + j], s_t1[cv + j], a.bn.relu);
+                stv<T>(y + (size_t)pix * C + cv, o);
+            } else if (OP == FPD_EW_BNRELU_BWD_R) {
+                float v[VEC], g[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+                ldv<T>(dy + (size_t)pix * C + cv, g);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float z = fmaf(v[j], s_t0[cv + j], s_t1[cv + j]);
+                    o[j] = (!a.bn.relu || z > 0.f) ? g[j] : 0.f;
+                    const float r = DT<T>::rnd(o[j]);
+                    acc1[j] += r;
+                    acc2[j] += r * ((v[j] - s_t2[cv + j]) * s_t3[cv + j]);
+                }
+                stv<T>(y + (size_t)pix * C + cv, o);
+            } else if (OP == FPD_EW_BN_BWD_APPLY) {
+                float v[VEC], g[VEC], ad[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+                ldv<T>(dy + (size_t)pix * C + cv, g);
+                if (add) ldv<T>(add + (size_t)pix * C + cv, ad);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int c = cv + j;
+                    const float xhat = (v[j] - s_t3[c]) * s_sum[0][c];
+                    o[j] = s_t0[c] * (g[j] - s_t1[c] - xhat * s_t2[c]) + (add ? ad[j] : 0.f);
+                }
+                stv<T>(y + (size_t)pix * C + cv, o);
+            } else if (OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_MAXPOOL_BWD || OP == FPD_EW_SUMPOOL) {
+                const int n = pix / (OH * OW), rem = pix - n * (OH * OW);
+                const int oy = rem / OW, ox = rem - oy * OW;
+                const size_t i00 = ((size_t)(n * H + 2 * oy) * W + 2 * ox) * C + cv;
+                const size_t i01 = i00 + C, i10 = i00 + (size_t)W * C, i11 = i10 + C;
+                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                ldv<T>(x + i00, v0); ldv<T>(x + i01, v1); ldv<T>(x + i10, v2); ldv<T>(x + i11, v3);
+                if (OP == FPD_EW_MAXPOOL_FWD) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] = fmaxf(fmaxf(v0[j], v1[j]), fmaxf(v2[j], v3[j]));
+                    stv<T>(y + (size_t)pix * C + cv, o);
+                } else if (OP == FPD_EW_SUMPOOL) {
+                    float ad[VEC];
+                    if (add) ldv<T>(add + (size_t)pix * C + cv, ad);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] = (v0[j] + v1[j]) + (v2[j] + v3[j]) + (add ? ad[j] : 0.f);
+                    stv<T>(y + (size_t)pix * C + cv, o);
+                } else {  // MAXPOOL_BWD: route dy to the first maximum in scan order (torch max_pool2d semantics)
+                    float g[VEC], a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+                    ldv<T>(dy + (size_t)pix * C + cv, g);
+                    if (add) { ldv<T>(add + i00, a0); ldv<T>(add + i01, a1); ldv<T>(add + i10, a2); ldv<T>(add + i11, a3); }
+                    float o0[VEC], o1[VEC], o2[VEC], o3[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        int arg = 0; float best = v0[j];
+                        if (v1[j] > best) { best = v1[j]; arg = 1; }
+                        if (v2[j] > best) { best = v2[j]; arg = 2; }
+                        if (v3[j] > best) { best = v3[j]; arg = 3; }
+                        o0[j] = (arg == 0 ? g[j] : 0.f) + (add ? a0[j] : 0.f);
+                        o1[j] = (arg == 1 ? g[j] : 0.f) + (add ? a1[j] : 0.f);
+                        o2[j] = (arg == 2 ? g[j] : 0.f) + (add ? a2[j] : 0.f);
+                        o3[j] = (arg == 3 ? g[j] : 0.f) + (add ? a3[j] : 0.f);
+                    }
+                    stv<T>(y + i00, o0); stv<T>(y + i01, o1); stv<T>(y + i10, o2); stv<T>(y + i11, o3);
+                }
+            } else if (OP == FPD_EW_UPADD_FWD) {
+                const int n = pix / (H * W), rem = pix - n * (H * W);
+                const int oy = rem / W, ox = rem - oy * W;
+                float v[VEC], u[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+                ldv<T>(x2 + ((size_t)(n * (H / 2) + oy / 2) * (W / 2) + ox / 2) * C + cv, u);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = v[j] + u[j];
+                stv<T>(y + (size_t)pix * C + cv, o);
+            } else {  // ADD
+                float v[VEC], u[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+                ldv<T>(x2 + (size_t)pix * C + cv, u);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = v[j] + u[j];
+                stv<T>(y + (size_t)pix * C + cv, o);
+            }
+            if (STATS && do_stats) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { const float r = DT<T>::rnd(o[j]); acc1[j] += r; acc2[j] += r * r; }
+            }
+        }
+    }
+    if (do_stats) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { atomicAdd(&s_sum[0][cv + j], acc1[j]); atomicAdd(&s_sum[1][cv + j], acc2[j]); }
+        }
+        __syncthreads();
+        double* dst = STATS ? a.out_stats : a.bstats;
+        for (int c = tid; c < C; c += 256) {
+            atomicAdd(dst + c, (double)s_sum[0][c]);
+            atomicAdd(dst + C + c, (double)s_sum[1][c]);
+        }
+    }
+}
+
+template <typename T, int OP>
+int launch_ew(const fpd_ew_t& a, hipStream_t st) {
+    constexpr int VEC = DT<T>::VEC;
+    const int VP = a.C / VEC, PB = 256 / VP;
+    const bool half = (OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_MAXPOOL_BWD || OP == FPD_EW_SUMPOOL);
+    const int npix = a.N * (half ? a.H / 2 : a.H) * (half ? a.W / 2 : a.W);
+    const int grid = std::max(1, std::min(cdiv(npix, PB), 2048));
+    hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+
+template <typename T>
+int dispatch_ew(const fpd_ew_t& a, hipStream_t st) {
+    switch (a.op) {
+        case FPD_EW_BNRELU_FWD: return launch_ew<T, FPD_EW_BNRELU_FWD>(a, st);
+        case FPD_EW_BNRELU_BWD_R: return launch_ew<T, FPD_EW_BNRELU_BWD_R>(a, st);
+        case FPD_EW_BN_BWD_APPLY: return launch_ew<T, FPD_EW_BN_BWD_APPLY>(a, st);
+        case FPD_EW_MAXPOOL_FWD: return launch_ew<T, FPD_EW_MAXPOOL_FWD>(a, st);
+        case FPD_EW_MAXPOOL_BWD: return launch_ew<T, FPD_EW_MAXPOOL_BWD>(a, st);
+        case FPD_EW_UPADD_FWD: return launch_ew<T, FPD_EW_UPADD_FWD>(a, st);
+        case FPD_EW_SUMPOOL: return launch_ew<T, FPD_EW_SUMPOOL>(a, st);
+        case FPD_EW_ADD: return launch_ew<T, FPD_EW_ADD>(a, st);
+    }
+    return fpd_fail(-2, "elementwise: unknown op %d", a.op);
+}
+
+}  // namespace
+
+int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st) {
+    const int vec = (a.dtype == FPD_BF16) ? 8 : 4;
+    if (a.C % vec != 0 || a.C > FPD_MAXC || a.C / vec > 128)
+        return fpd_fail(-3, "elementwise: C=%d must be a multiple of %d and <= %d", a.C, vec, FPD_MAXC);
+    const bool pooled = (a.op == FPD_EW_MAXPOOL_FWD || a.op == FPD_EW_MAXPOOL_BWD || a.op == FPD_EW_SUMPOOL ||
+                         a.op == FPD_EW_UPADD_FWD);
+    if (pooled && ((a.H & 1) || (a.W & 1))) return fpd_fail(-3, "elementwise: 2x2 ops need even H,W (got %dx%d)", a.H, a.W);
+    return a.dtype == FPD_BF16 ? dispatch_ew<bf16_t>(a, st) : dispatch_ew<float>(a, st);
+}

@@ -1,0 +1,212 @@
+// Fused JointsMSELoss (pose + distillation, all stacks, forward + gradient in one pass), flat Adam,
+// weight working-copy preparation, BN running-statistics update, casts and layout changes.
+// Replaces /root/reference/lib/core/loss.py:21-39 as called from lib/core/function.py:128-134 (2*S
+// criterion calls + autograd), torch.optim.Adam (lib/utils/utils.py:69-73) and the running-stat side
+// effect of nn.BatchNorm2d(momentum=0.1) (lib/models/hourglass.py:10).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+// Block = 64 consecutive pixels of one image x all J joints.  The fp32 target arrives in the loader's
+// NCHW layout; it is read coalesced along hw and turned through LDS so the NHWC maps are read/written
+// with consecutive lanes on consecutive joints.
+template <typename T>
+__global__ __launch_bounds__(256) void loss_kernel(const fpd_loss_t a) {
+    constexpr int PT = 64;
+    __shared__ float s_tg[PT * 33];       // [pixel][joint] with J <= 32, padded rows
+    __shared__ double s_acc[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int J = a.J, HW = a.H * a.W;
+    const int tiles_per_img = (HW + PT - 1) / PT;
+    const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * PT;
+    const int LDJ = J + 1;
+    if (a.target_nchw) {
+        for (int i = tid; i < J * PT; i += 256) {
+            const int j = i / PT, p = i - j * PT;
+            s_tg[p * LDJ + j] = (p0 + p < HW) ? a.target[((size_t)b * J + j) * HW + p0 + p] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < J * PT; i += 256) {
+            const int p = i / J, j = i - p * J;
+            s_tg[p * LDJ + j] = (p0 + p < HW) ? a.target[((size_t)b * HW + p0 + p) * J + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    const double cnt = (double)a.B * J * HW;
+    const float gs = a.grad_scale / (float)cnt;
+    const T* tch = reinterpret_cast<const T*>(a.teacher);
+    float pose = 0.f, kd = 0.f;
+    for (int i = tid; i < J * PT; i += 256) {
+        const int p = i / J, j = i - p * J;
+        if (p0 + p >= HW) continue;
+        const size_t off = ((size_t)b * HW + p0 + p) * J + j;
+        const float wgt = a.weight[b * J + j], w2 = wgt * wgt;
+        const float g = s_tg[p * LDJ + j];
+        const float t = DT<T>::ld(tch + off);
+        for (int s = 0; s < a.S; ++s) {
+            const float pv = DT<T>::ld(reinterpret_cast<const T*>(a.out[s]) + off);
+            const float dg = pv - g, dt = pv - t;
+            pose += w2 * dg * dg;
+            kd += w2 * dt * dt;
+            if (a.dout[s] != nullptr)
+                DT<T>::st(reinterpret_cast<T*>(a.dout[s]) + off, gs * w2 * ((1.f - a.alpha) * dg + a.alpha * dt));
+        }
+    }
+    const double dp = wave_sum_d((double)pose), dk = wave_sum_d((double)kd);
+    if (lane == 0) { s_acc[0][wave] = dp; s_acc[1][wave] = dk; }
+    __syncthreads();
+    if (tid == 0) {
+        const double sc = 0.5 / cnt;
+        atomicAdd(a.losses + 0, sc * (s_acc[0][0] + s_acc[0][1] + s_acc[0][2] + s_acc[0][3]));
+        atomicAdd(a.losses + 1, sc * (s_acc[1][0] + s_acc[1][1] + s_acc[1][2] + s_acc[1][3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const fpd_adam_t a) {
+    float bc1 = a.bias_corr1, bc2 = a.bias_corr2, lr = a.lr;
+    if (a.step_dev != nullptr) {
+        const double t = (double)(*a.step_dev + 1);
+        bc1 = (float)(1.0 - pow((double)a.beta1, t));
+        bc2 = (float)(1.0 - pow((double)a.beta2, t));
+    }
+    if (a.lr_dev != nullptr) lr = *a.lr_dev;
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    bf16_t* lp = reinterpret_cast<bf16_t*>(a.param_lp);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = a.grad[i] * a.grad_scale;
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+        const float p = a.param[i] - step_size * (m / denom);
+        a.m[i] = m; a.v[i] = v; a.param[i] = p;
+        if (lp) lp[i] = f2bf(p);
+    }
+}
+__global__ void adam_tick_kernel(int64_t* step) { *step += 1; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void wprep_kernel(const fpd_wprep_entry_t* table) {
+    const fpd_wprep_entry_t e = table[blockIdx.y];
+    const int K = e.K, R = e.R, S = e.S, C = e.C;
+    const int total = K * R * S * C;
+    T* wf = reinterpret_cast<T*>(e.w_fwd);
+    T* wb = reinterpret_cast<T*>(e.w_bwd);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const float v = e.w[i];
+        if (wf) DT<T>::st(wf + i, v);
+        if (wb) {
+            const int c = i % C, s = (i / C) % S, r = (i / (C * S)) % R, k = i / (C * S * R);
+            DT<T>::st(wb + ((size_t)(c * R + (R - 1 - r)) * S + (S - 1 - s)) * K + k, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bnupd_kernel(const fpd_bnupd_entry_t* table) {
+    const fpd_bnupd_entry_t e = table[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        const double mean = e.stats[c] / e.count;
+        double var = e.stats[e.C + c] / e.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unb = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
+        e.running_mean[c] = (float)((1.0 - e.momentum) * (double)e.running_mean[c] + e.momentum * mean);
+        e.running_var[c] = (float)((1.0 - e.momentum) * (double)e.running_var[c] + e.momentum * unb);
+    }
+    if (threadIdx.x == 0 && e.num_batches_tracked != nullptr) *e.num_batches_tracked += 1;
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* s, TD* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        DT<TD>::st(d + i, DT<TS>::ld(s + i));
+}
+
+// out[n][h][w][c] = in[n][c][h][w]   (thread per output element; small tensors only)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int N, int C, int H, int W) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int hw = (int)(pix % ((int64_t)H * W)), n = (int)(pix / ((int64_t)H * W));
+        DT<T>::st(dst + i, src[((int64_t)n * C + c) * H * W + hw]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int N, int C, int H, int W) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % ((int64_t)H * W));
+        const int64_t nc = i / ((int64_t)H * W);
+        const int c = (int)(nc % C), n = (int)(nc / C);
+        dst[i] = DT<T>::ld(src + ((int64_t)n * H * W + hw) * C + c);
+    }
+}
+
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+
+}  // namespace
+
+int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st) {
+    if (a.J > 32 || a.S > FPD_MAX_STACKS || a.S < 1) return fpd_fail(-3, "loss: J=%d (<=32), S=%d (1..%d)", a.J, a.S, FPD_MAX_STACKS);
+    const int tiles = a.B * cdiv(a.H * a.W, 64);
+    if (a.dtype == FPD_BF16)
+        hipLaunchKernelGGL((loss_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((loss_kernel<float>), dim3(tiles), dim3(256), 0, st, a);
+    return 0;
+}
+
+int fpd_adam_launch(const fpd_adam_t& a, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n)), dim3(256), 0, st, a);
+    if (a.step_dev != nullptr) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, a.step_dev);
+    return 0;
+}
+
+int fpd_weight_prep_launch(const fpd_wprep_entry_t* table, int n, int64_t max_elems, int dtype, hipStream_t st) {
+    if (n <= 0) return 0;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 255) / 256, 256)), (unsigned)n);
+    if (dtype == FPD_BF16)
+        hipLaunchKernelGGL((wprep_kernel<bf16_t>), grid, dim3(256), 0, st, table);
+    else
+        hipLaunchKernelGGL((wprep_kernel<float>), grid, dim3(256), 0, st, table);
+    return 0;
+}
+
+int fpd_bn_update_running_launch(const fpd_bnupd_entry_t* table, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(bnupd_kernel, dim3(n), dim3(256), 0, st, table);
+    return 0;
+}
+
+int fpd_cast_launch(const void* src, void* dst, int64_t n, int sd, int dd, hipStream_t st) {
+    const int g = grid_for(n);
+    if (sd == FPD_F32 && dd == FPD_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == FPD_BF16 && dd == FPD_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == FPD_F32 && dd == FPD_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    return 0;
+}
+
+int fpd_nchw_to_nhwc_launch(const float* src, void* dst, int N, int C, int H, int W, int dtype, hipStream_t st) {
+    const int g = grid_for((int64_t)N * C * H * W);
+    if (dtype == FPD_BF16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, N, C, H, W);
+    else
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(g), dim3(256), 0, st, src, (float*)dst, N, C, H, W);
+    return 0;
+}
+
+int fpd_nhwc_to_nchw_launch(const void* src, float* dst, int N, int C, int H, int W, int dtype, hipStream_t st) {
+    const int g = grid_for((int64_t)N * C * H * W);
+    if (dtype == FPD_BF16)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, H, W);
+    else
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, dst, N, C, H, W);
+    return 0;
+}

@@ -1,0 +1,449 @@
+"""Host-side graph of the FPD hot path: op list (IR), reverse-mode construction, memory planning.
+
+Pure Python, no torch/GPU dependency: the same IR is lowered to the C ABI (executor.py) for the
+MI355X, and interpreted on CPU by the test oracle (oracle/plan_interp.py) to check this host logic.
+
+What is mirrored from the reference (citations into /root/reference):
+  * lib/models/hourglass.py:32-52   Bottleneck   -> HourglassGraph.bottleneck
+  * lib/models/hourglass.py:80-92   Hourglass    -> HourglassGraph.hour_glass
+  * lib/models/hourglass.py:170-192 HourglassNet -> HourglassGraph.build_forward
+  * autograd of all of the above                 -> HourglassGraph.build_backward
+Design (MI355X-first): every BatchNorm+ReLU is folded into the *consumer* conv's
+operand load; every producer accumulates the batch statistics the next BN needs in its epilogue;
+activations are NHWC; tensors are placed in one arena by liveness over the whole fwd+bwd list.
+"""
+from collections import OrderedDict
+
+BN_EPS = 1e-5        # torch default, hourglass.py:18
+BN_MOMENTUM = 0.1    # hourglass.py:10
+
+
+class Buf:
+    """A region of a named flat arena (offset/size in elements)."""
+    __slots__ = ('arena', 'off', 'shape', 'name')
+
+    def __init__(self, arena, off, shape, name=''):
+        self.arena, self.off, self.shape, self.name = arena, off, tuple(shape), name
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def __repr__(self):
+        return 'Buf(%s+%s %s %s)' % (self.arena, self.off, self.shape, self.name)
+
+
+class Act:
+    """NHWC activation (or activation-gradient) tensor; `buf` is assigned by plan_memory()."""
+    __slots__ = ('shape', 'buf', 'stats', 'producer', 'grad', 'name', 'persistent', 'needs_grad')
+
+    def __init__(self, shape, name=''):
+        self.shape = tuple(shape)      # (N,H,W,C)
+        self.buf = None
+        self.stats = None              # Buf in 'stats' arena: [2*C] fp64 {sum, sumsq}
+        self.producer = None
+        self.grad = None               # Act
+        self.name = name
+        self.persistent = False
+        self.needs_grad = True
+
+    @property
+    def numel(self):
+        n, h, w, c = self.shape
+        return n * h * w * c
+
+
+class BN:
+    __slots__ = ('name', 'mode', 'relu', 'C', 'gamma', 'beta', 'rmean', 'rvar', 'nbt', 'stats', 'count')
+
+    def __init__(self, name, mode, C, gamma, beta, rmean, rvar, nbt, stats=None, relu=True):
+        self.name, self.mode, self.C, self.relu = name, mode, C, relu
+        self.gamma, self.beta, self.rmean, self.rvar, self.nbt, self.stats = gamma, beta, rmean, rvar, nbt, stats
+        self.count = 0                 # N*H*W of the normalised tensor
+
+
+class Op:
+    """kind in {conv, wgrad, stem_fwd, stem_wgrad, ew, loss, adam, memset, wprep, bnupd}; free-form fields."""
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+    def acts_in(self):
+        return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
+                isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None]
+
+    def acts_out(self):
+        return [getattr(self, f) for f in ('y',) if isinstance(getattr(self, f, None), Act)] + \
+               [a for a in getattr(self, 'extra_out', []) if a is not None]
+
+
+# ------------------------------------------------------------------------------------------------
+# parameters
+# ------------------------------------------------------------------------------------------------
+class ParamTable:
+    """Flat layout of a model's state_dict.  'param' arena: trainable tensors (conv weights stored
+    K,R,S,C = the OIHW tensor in channels-last memory order; biases; BN affine) in state_dict order;
+    'rstat': BN running mean/var; 'nbt': num_batches_tracked."""
+
+    def __init__(self, keys):
+        self.keys = list(keys)                     # [(key, logical_shape)]
+        self.entries = OrderedDict()               # key -> Buf
+        self.logical = dict(self.keys)
+        self.sizes = {'param': 0, 'rstat': 0, 'nbt': 0}
+        for k, shp in self.keys:
+            if k.endswith('num_batches_tracked'):
+                arena = 'nbt'
+            elif k.endswith('running_mean') or k.endswith('running_var'):
+                arena = 'rstat'
+            else:
+                arena = 'param'
+            n = 1
+            for s in shp:
+                n *= s
+            phys = (shp[0], shp[2], shp[3], shp[1]) if len(shp) == 4 else tuple(shp)
+            off = self.sizes[arena]
+            self.entries[k] = Buf(arena, off, phys, k)
+            # keep every tensor 16-byte aligned in its arena
+            step = 4 if arena != 'nbt' else 2
+            self.sizes[arena] = off + (n + step - 1) // step * step
+
+    def __getitem__(self, k):
+        return self.entries[k]
+
+    def grad(self, k):
+        b = self.entries[k]
+        return Buf('grad', b.off, b.shape, 'grad:' + k)
+
+    def conv_keys(self):
+        return [k for k, shp in self.keys if len(shp) == 4]
+
+    def trainable_keys(self):
+        return [k for k, b in self.entries.items() if b.arena == 'param']
+
+
+# ------------------------------------------------------------------------------------------------
+# memory planning
+# ------------------------------------------------------------------------------------------------
+def plan_memory(ops, align=64):
+    """Assign every Act reachable from `ops` an offset in the 'act' arena by liveness: a tensor is
+    allocated at its first appearance and released after the last op that mentions it (persistent
+    tensors never).  Outputs of an op are placed before its inputs are released, so an op never
+    overwrites its own inputs unless the IR aliases them on purpose.  Returns the arena size."""
+    last = {}
+    for i, op in enumerate(ops):
+        for a in op.acts_in() + op.acts_out():
+            last[id(a)] = i
+    free = []      # list of (off, size)
+    top = 0
+
+    def alloc(n):
+        nonlocal top
+        n = (n + align - 1) // align * align
+        best = None
+        for j, (o, s) in enumerate(free):
+            if s >= n and (best is None or s < free[best][1]):
+                best = j
+        if best is not None:
+            o, s = free.pop(best)
+            if s > n:
+                free.append((o + n, s - n))
+            return o, n
+        o = top
+        top += n
+        return o, n
+
+    def release(o, n):
+        free.append((o, n))
+        free.sort()
+        merged = []
+        for o2, s2 in free:
+            if merged and merged[-1][0] + merged[-1][1] == o2:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s2)
+            else:
+                merged.append((o2, s2))
+        free[:] = merged
+
+    sizes = {}
+    for i, op in enumerate(ops):
+        for a in op.acts_in() + op.acts_out():
+            if a.buf is None:
+                o, n = alloc(a.numel)
+                a.buf = Buf('act', o, a.shape, a.name)
+                sizes[id(a)] = n
+        seen = set()
+        for a in op.acts_in() + op.acts_out():
+            if id(a) in seen:
+                continue
+            seen.add(id(a))
+            if last[id(a)] == i and not a.persistent and id(a) in sizes:
+                release(a.buf.off, sizes.pop(id(a)))
+    return top
+
+
+# ------------------------------------------------------------------------------------------------
+# hourglass graph
+# ------------------------------------------------------------------------------------------------
+class HourglassGraph:
+    """Op lists for one (model, batch shape, train|eval) instance."""
+
+    def __init__(self, params, num_feats, num_stacks, num_joints, batch, height, width, train, num_blocks=1,
+                 depth=4, wlp_is_master=True):
+        self.p = params
+        self.F, self.S, self.J = num_feats, num_stacks, num_joints
+        self.N, self.H, self.W = batch, height, width
+        self.train, self.num_blocks, self.depth = train, num_blocks, depth
+        self.wlp_is_master = wlp_is_master     # fp32 build: forward convs read the master weights directly
+        self.stats_size = 0
+        self.wlp_size = 0
+        self.wfwd, self.wbwd = {}, {}
+        self.fwd, self.bwd = [], []
+        self.bns = []                          # train-mode BNs in forward order (running-stat update table)
+        self.image = Buf('image', 0, (batch, 3, height, width), 'image')
+        self.outputs = []
+        self._bn_pending = {}
+        self._bn_uses = {}
+        for k in self.p.conv_keys():
+            if k == 'conv1.weight':
+                continue                       # stem reads the fp32 master weights
+            b = self.p[k]
+            if not wlp_is_master:
+                self.wfwd[k] = self._wlp(b)
+            if train:
+                K, R, S, C = b.shape
+                self.wbwd[k] = self._wlp(Buf('param', 0, (C, R, S, K)))
+        self.build_forward()
+        if train:
+            self.build_backward()
+
+    # ---- small allocators ----
+    def _wlp(self, like):
+        off = self.wlp_size
+        self.wlp_size += (like.numel + 7) // 8 * 8
+        return Buf('wlp', off, like.shape, 'wlp')
+
+    def _stats(self, C, name=''):
+        off = self.stats_size
+        self.stats_size += 2 * C
+        return Buf('stats', off, (2, C), name)
+
+    def _bn(self, name, C):
+        g = self.p
+        mode = 'train' if self.train else 'eval'
+        return BN(name, mode, C, g[name + '.weight'], g[name + '.bias'], g[name + '.running_mean'],
+                  g[name + '.running_var'], g[name + '.num_batches_tracked'])
+
+    # ---- forward primitives ----
+    def conv(self, x, name, bn=None, residual=None, pad=0):
+        wkey = name + '.weight'
+        K, R, S, C = self.p[wkey].shape
+        n, h, w, c = x.shape
+        assert c == C, (name, x.shape, self.p[wkey].shape)
+        y = Act((n, h + 2 * pad - R + 1, w + 2 * pad - S + 1, K), name)
+        wbuf = self.p[wkey] if self.wlp_is_master else self.wfwd[wkey]
+        op = Op('conv', x=x, w=wbuf, wkey=wkey, bias=self.p[name + '.bias'], bkey=name + '.bias', residual=residual,
+                y=y, out_stats=None, bn=bn, epi='plain', epi_x=None, epi_bn=None, epi_stats=None,
+                dims=(n, h, w, C, K, R, S, 1, pad, y.shape[1], y.shape[2]))
+        y.producer = op
+        if bn is not None:
+            self._use_bn(x, bn)
+        self.fwd.append(op)
+        return y
+
+    def _use_bn(self, x, bn):
+        if bn.mode == 'train':
+            if x.stats is None:
+                x.stats = self._stats(x.shape[3], 'stats:' + x.name)
+                prod = x.producer
+                assert prod is not None and hasattr(prod, 'out_stats'), 'no stats producer for ' + x.name
+                prod.out_stats = x.stats
+            bn.stats = x.stats
+            key = (id(x), bn.name)
+            self._bn_uses[key] = self._bn_uses.get(key, 0) + 1
+            if not any(b.name == bn.name for b in self.bns):
+                self.bns.append(bn)
+        bn.count = x.shape[0] * x.shape[1] * x.shape[2]
+        return bn
+
+    def ew(self, opname, shape_large, y_shape, name, **kw):
+        y = Act(y_shape, name)
+        op = Op('ew', op=opname, dims=tuple(shape_large), y=y, out_stats=None, x=kw.get('x'), x2=kw.get('x2'),
+                dy=None, add=None, bstats=None, dgamma=None, dbeta=None, bn=kw.get('bn'))
+        y.producer = op
+        self.fwd.append(op)
+        return y
+
+    def maxpool(self, x, name):
+        n, h, w, c = x.shape
+        return self.ew('maxpool_fwd', x.shape, (n, h // 2, w // 2, c), name, x=x)
+
+    def upadd(self, a, b, name):
+        assert a.shape[1] == 2 * b.shape[1] and a.shape[2] == 2 * b.shape[2] and a.shape[3] == b.shape[3]
+        return self.ew('upadd_fwd', a.shape, a.shape, name, x=a, x2=b)
+
+    def bottleneck(self, x, p):
+        """hourglass.py:32-52 with bn_k+relu folded into conv_k's operand load."""
+        c_in = x.shape[3]
+        planes = self.p[p + 'conv1.weight'].shape[0]
+        t = self.conv(x, p + 'conv1', bn=self._bn(p + 'bn1', c_in))
+        t = self.conv(t, p + 'conv2', bn=self._bn(p + 'bn2', planes), pad=1)
+        skip = x
+        if (p + 'downsample.0.weight') in self.p.entries:
+            skip = self.conv(x, p + 'downsample.0')
+        return self.conv(t, p + 'conv3', bn=self._bn(p + 'bn3', planes), residual=skip)
+
+    def residual_seq(self, x, p, nb):
+        for b in range(nb):
+            x = self.bottleneck(x, '%s%d.' % (p, b))
+        return x
+
+    def hour_glass(self, x, p, n):
+        """hourglass.py:80-92."""
+        q = '%s%d.' % (p, n - 1)
+        nb = self.num_blocks
+        up1 = self.residual_seq(x, q + '0.', nb)
+        low = self.maxpool(x, q + 'pool')
+        low = self.residual_seq(low, q + '1.', nb)
+        if n > 1:
+            low = self.hour_glass(low, p, n - 1)
+        else:
+            low = self.residual_seq(low, q + '3.', nb)
+        low = self.residual_seq(low, q + '2.', nb)
+        return self.upadd(up1, low, q + 'upadd')
+
+    def build_forward(self):
+        """hourglass.py:170-192."""
+        K = self.p['conv1.weight'].shape[0]
+        P, Q = (self.H + 6 - 7) // 2 + 1, (self.W + 6 - 7) // 2 + 1
+        x = Act((self.N, P, Q, K), 'stem')
+        op = Op('stem_fwd', image=self.image, w=self.p['conv1.weight'], bias=self.p['conv1.bias'], y=x, out_stats=None,
+                dims=(self.N, self.H, self.W, K, P, Q))
+        x.producer = op
+        self.fwd.append(op)
+        bn1 = self._bn('bn1', K)
+        self._use_bn(x, bn1)
+        x = self.ew('bnrelu_fwd', x.shape, x.shape, 'stem_act', x=x, bn=bn1)
+        x = self.residual_seq(x, 'layer1.', 1)
+        x = self.maxpool(x, 'pool1')
+        x = self.residual_seq(x, 'layer2.', 1)
+        x = self.residual_seq(x, 'layer3.', 1)
+        ch = x.shape[3]
+        for i in range(self.S):
+            y = self.hour_glass(x, 'hg.%d.hg.' % i, self.depth)
+            y = self.residual_seq(y, 'res.%d.' % i, self.num_blocks)
+            y = self.conv(y, 'fc.%d.0' % i)
+            fcbn = self._bn('fc.%d.1' % i, ch)
+            score = self.conv(y, 'score.%d' % i, bn=fcbn)
+            score.persistent = True
+            self.outputs.append(score)
+            if i < self.S - 1:
+                fcbn2 = self._bn('fc.%d.1' % i, ch)
+                t = self.conv(y, 'fc_.%d' % i, bn=fcbn2, residual=x)
+                x = self.conv(score, 'score_.%d' % i, residual=t)
+        if self.train:
+            self.fwd.append(Op('bnupd', bns=list(self.bns)))
+
+    # ---- backward construction ----
+    def _contribute(self, t):
+        """(add_src, out) for an op that writes out = add_src + <its contribution to dL/dt>."""
+        if t.grad is None:
+            t.grad = Act(t.shape, 'd:' + t.name)
+            return None, t.grad
+        return t.grad, t.grad
+
+    def _contribute_identity(self, t, g):
+        if t.grad is None:
+            t.grad = g                      # alias: g is final, later contributions accumulate in place
+        else:
+            self.bwd.append(Op('ew', op='add', dims=t.shape, x=t.grad, x2=g, y=t.grad, dy=None, add=None,
+                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None))
+
+    def _bn_backward_contribution(self, x, bn, make_dgrad):
+        """Route a gradient through the fused BN+ReLU prologue of tensor x.  `make_dgrad(dz, add, bstats)`
+        emits the op producing dz = relu'(.) * dA (accumulated onto `add`) and the sums into bstats."""
+        key = (id(x), bn.name)
+        pend = self._bn_pending.get(key)
+        bstats = self._stats(bn.C, 'bstats:' + bn.name)
+        if pend is None:
+            dz = Act(x.shape, 'dz:' + bn.name)
+            make_dgrad(dz, None, bstats)
+            pend = {'dz': dz, 'left': self._bn_uses[key]}
+            self._bn_pending[key] = pend
+        else:
+            make_dgrad(pend['dz'], pend['dz'], bstats)       # mask(acc + dz_prev) == mask(acc) + dz_prev
+        pend['left'] -= 1
+        if pend['left'] == 0:
+            add, out = self._contribute(x)
+            self.bwd.append(Op('ew', op='bn_bwd_apply', dims=x.shape, x=x, x2=None, dy=pend['dz'], add=add, y=out,
+                               out_stats=None, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
+                               dbeta=self.p.grad(bn.name + '.bias'), bn=bn))
+            del self._bn_pending[key]
+
+    def build_backward(self):
+        self.out_grads = []
+        for o in self.outputs:
+            o.grad = Act(o.shape, 'd:' + o.name)
+            o.grad.persistent = True
+            self.out_grads.append(o.grad)
+        for op in reversed(self.fwd):
+            if op.kind == 'conv':
+                self._conv_backward(op)
+            elif op.kind == 'stem_fwd':
+                dy = op.y.grad
+                self.bwd.append(Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
+                                   dbias=self.p.grad('conv1.bias'), dims=op.dims))
+            elif op.kind == 'ew':
+                self._ew_backward(op)
+        assert not self._bn_pending, 'unfinished BN backward: %r' % list(self._bn_pending)
+
+    def _conv_backward(self, op):
+        dy = op.y.grad
+        if dy is None:
+            return
+        x = op.x
+        self.bwd.append(Op('wgrad', x=x, dy=dy, dw=self.p.grad(op.wkey), dbias=self.p.grad(op.bkey), bn=op.bn,
+                           dims=op.dims))
+        if op.residual is not None:
+            self._contribute_identity(op.residual, dy)
+        if not x.needs_grad:
+            return
+        n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
+        ddims = (n, P, Q, K, C, R, S, 1, R - 1 - pad, h, w)      # dgrad = conv of dy with the flipped IO-swapped weights
+        wb = self.wbwd[op.wkey]
+        if op.bn is not None:
+            def make(dz, add, bstats, op=op, dy=dy, x=x):
+                self.bwd.append(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=dz,
+                                   out_stats=None, bn=None, epi='bnrelu_bwd', epi_x=x, epi_bn=op.bn, epi_stats=bstats,
+                                   dims=ddims))
+            self._bn_backward_contribution(x, op.bn, make)
+        else:
+            add, out = self._contribute(x)
+            self.bwd.append(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=out,
+                               out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims))
+
+    def _ew_backward(self, op):
+        dy = op.y.grad
+        if dy is None:
+            return
+        if op.op == 'maxpool_fwd':
+            add, out = self._contribute(op.x)
+            self.bwd.append(Op('ew', op='maxpool_bwd', dims=op.dims, x=op.x, x2=None, dy=dy, add=add, y=out,
+                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None))
+        elif op.op == 'upadd_fwd':
+            self._contribute_identity(op.x, dy)
+            add, out = self._contribute(op.x2)
+            self.bwd.append(Op('ew', op='sumpool', dims=op.dims, x=dy, x2=None, dy=None, add=add, y=out,
+                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None))
+        elif op.op == 'bnrelu_fwd':
+            x, bn = op.x, op.bn
+
+            def make(dz, add, bstats, dy=dy, x=x, bn=bn):
+                assert add is None
+                self.bwd.append(Op('ew', op='bnrelu_bwd_r', dims=x.shape, x=x, x2=None, dy=dy, add=None, y=dz,
+                                   out_stats=None, bstats=bstats, dgamma=None, dbeta=None, bn=bn))
+            self._bn_backward_contribution(x, bn, make)
+        else:
+            raise AssertionError(op.op)

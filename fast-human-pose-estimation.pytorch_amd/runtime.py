@@ -1,0 +1,199 @@
+"""ctypes binding of libfpd_amd.so (include/fpd_amd.h).
+
+The library is the product: if it is missing or an ABI struct size disagrees, import fails loudly
+-- there is no CPU / eager fallback (build with `python __graft_entry__.py` or csrc/build.sh).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libfpd_amd.so')
+
+F32, BF16 = 0, 1
+BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
+EPI_PLAIN, EPI_BNRELU_BWD = 0, 1
+BACKEND_MFMA, BACKEND_NAIVE = 0, 1
+(EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
+ EW_ADD) = range(8)
+(OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD) = range(10)
+MAX_STACKS = 8
+MAXC = 512
+
+_i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class BnT(C.Structure):
+    _fields_ = [('mode', _i32), ('relu', _i32), ('eps', _f32), ('_pad', _i32), ('stats', _vp), ('gamma', _vp),
+                ('beta', _vp), ('running_mean', _vp), ('running_var', _vp)]
+
+
+class ConvT(C.Structure):
+    _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('K', _i32), ('R', _i32), ('S', _i32),
+                ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('epi', _i32),
+                ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('residual', _vp), ('y', _vp),
+                ('out_stats', _vp), ('bn', BnT), ('epi_x', _vp), ('epi_bn', BnT), ('epi_stats', _vp)]
+
+
+class WgradT(C.Structure):
+    _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('K', _i32), ('R', _i32), ('S', _i32),
+                ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('x', _vp), ('dy', _vp),
+                ('dw', _vp), ('dbias', _vp), ('bn', BnT)]
+
+
+class StemT(C.Structure):
+    _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('K', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32),
+                ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp), ('out_stats', _vp), ('dy', _vp),
+                ('dw', _vp), ('dbias', _vp)]
+
+
+class EwT(C.Structure):
+    _fields_ = [('op', _i32), ('dtype', _i32), ('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('x', _vp),
+                ('x2', _vp), ('dy', _vp), ('add', _vp), ('y', _vp), ('out_stats', _vp), ('bstats', _vp),
+                ('dgamma', _vp), ('dbeta', _vp), ('bn', BnT)]
+
+
+class LossT(C.Structure):
+    _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('S', _i32), ('dtype', _i32),
+                ('target_nchw', _i32), ('alpha', _f32), ('out', _vp * MAX_STACKS), ('dout', _vp * MAX_STACKS),
+                ('teacher', _vp), ('target', _vp), ('weight', _vp), ('losses', _vp), ('grad_scale', _f32),
+                ('_pad', _i32)]
+
+
+class AdamT(C.Structure):
+    _fields_ = [('n', _i64), ('param', _vp), ('grad', _vp), ('m', _vp), ('v', _vp), ('param_lp', _vp),
+                ('lr', _f32), ('beta1', _f32), ('beta2', _f32), ('eps', _f32), ('bias_corr1', _f32),
+                ('bias_corr2', _f32), ('grad_scale', _f32), ('_pad', _i32), ('lr_dev', _vp), ('step_dev', _vp)]
+
+
+class WprepEntryT(C.Structure):
+    _fields_ = [('w', _vp), ('w_fwd', _vp), ('w_bwd', _vp), ('K', _i32), ('R', _i32), ('S', _i32), ('C', _i32)]
+
+
+class BnupdEntryT(C.Structure):
+    _fields_ = [('stats', _vp), ('running_mean', _vp), ('running_var', _vp), ('num_batches_tracked', _vp),
+                ('count', _f64), ('momentum', _f32), ('C', _i32)]
+
+
+class MemsetT(C.Structure):
+    _fields_ = [('ptr', _vp), ('bytes', _i64)]
+
+
+class TableT(C.Structure):
+    _fields_ = [('table', _vp), ('n', _i32), ('dtype', _i32), ('max_elems', _i64)]
+
+
+_STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
+            'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
+            'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT}
+
+# every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'fpd_conv_forward': (C.c_int, [C.POINTER(ConvT), _vp]),
+    'fpd_conv_wgrad': (C.c_int, [C.POINTER(WgradT), _vp]),
+    'fpd_stem_forward': (C.c_int, [C.POINTER(StemT), _vp]),
+    'fpd_stem_wgrad': (C.c_int, [C.POINTER(StemT), _vp]),
+    'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),
+    'fpd_loss': (C.c_int, [C.POINTER(LossT), _vp]),
+    'fpd_adam': (C.c_int, [C.POINTER(AdamT), _vp]),
+    'fpd_weight_prep': (C.c_int, [_vp, _i32, _i64, _i32, _vp]),
+    'fpd_bn_update_running': (C.c_int, [_vp, _i32, _vp]),
+    'fpd_cast': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    'fpd_nchw_to_nhwc': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'fpd_nhwc_to_nchw': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'fpd_plan_create': (_vp, []),
+    'fpd_plan_destroy': (None, [_vp]),
+    'fpd_plan_add': (C.c_int, [_vp, _i32, _vp, _i64]),
+    'fpd_plan_size': (C.c_int, [_vp]),
+    'fpd_plan_run': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'fpd_plan_capture': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'fpd_plan_replay': (C.c_int, [_vp, _i32, _vp]),
+    'fpd_last_error': (C.c_char_p, []),
+    'fpd_set_backend': (C.c_int, [_i32]),
+    'fpd_abi_sizeof': (C.c_int, [C.c_char_p]),
+    'fpd_abi_version': (C.c_int, []),
+    'fpd_event_create': (_vp, []),
+    'fpd_event_record': (C.c_int, [_vp, _vp]),
+    'fpd_event_elapsed_ms': (C.c_float, [_vp, _vp]),
+    'fpd_event_destroy': (None, [_vp]),
+}
+
+_lib = None
+
+
+class FpdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libfpd_amd.so once; raise (never fall back) if it is absent or ABI-incompatible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FpdError('HIP extension %s is missing: run `python __graft_entry__.py` (build()) first; '
+                       'there is no CPU fallback for the FPD path' % LIB_PATH)
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(l, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    for name, st in _STRUCTS.items():
+        got = l.fpd_abi_sizeof(name.encode())
+        if got != C.sizeof(st):
+            raise FpdError('ABI mismatch for %s: library %d bytes, python %d bytes' % (name, got, C.sizeof(st)))
+    _lib = l
+    return l
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise FpdError('%s failed (rc=%d): %s' % (what or 'fpd call', rc, lib().fpd_last_error().decode()))
+
+
+def set_backend(backend):
+    return lib().fpd_set_backend(backend)
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Owns a native fpd_plan (recorded op list) and the ctypes arg structs' lifetime."""
+
+    def __init__(self):
+        self._l = lib()
+        self._p = C.c_void_p(self._l.fpd_plan_create())
+        self._graphs = {}
+
+    def add(self, op, args):
+        rc = self._l.fpd_plan_add(self._p, op, C.byref(args), C.sizeof(args))
+        if rc < 0:
+            check(rc, 'fpd_plan_add')
+        return rc
+
+    def __len__(self):
+        return self._l.fpd_plan_size(self._p)
+
+    def run(self, begin, end, stream=None):
+        check(self._l.fpd_plan_run(self._p, begin, end, stream if stream is not None else current_stream()),
+              'fpd_plan_run')
+
+    def capture(self, begin, end, stream):
+        gid = self._l.fpd_plan_capture(self._p, begin, end, stream)
+        if gid < 0:
+            check(gid, 'fpd_plan_capture')
+        return gid
+
+    def replay(self, gid, stream=None):
+        check(self._l.fpd_plan_replay(self._p, gid, stream if stream is not None else current_stream()),
+              'fpd_plan_replay')
+
+    def __del__(self):
+        try:
+            if self._p:
+                self._l.fpd_plan_destroy(self._p)
+                self._p = None
+        except Exception:
+            pass

@@ -1,0 +1,232 @@
+/*
+ * fpd_amd.h -- C ABI of the MI355X (gfx950) Fast-Pose-Distillation training path.
+ *
+ * The reference (ilovepose/fast-human-pose-estimation.pytorch) has NO native/FFI interface on
+ * this path: its boundary is the Python module API (lib/models/hourglass.py:170-197,
+ * lib/core/loss.py:15-39, lib/core/function.py:99-187) and all arithmetic is torch.nn
+ * (cuDNN/ATen).  This header therefore DEFINES the boundary a maintainer would bind from
+ * Python (ctypes stub in INTEGRATION.md).  Each entry point names the reference call site
+ * whose arithmetic it replaces.
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no torch types; the CALLER owns every buffer (incl. workspaces);
+ *   - every call is asynchronous on the given hipStream_t, never synchronises, never allocates;
+ *   - return 0 on success, negative on error; fpd_last_error() gives a thread-local message;
+ *   - activations are NHWC ("channels last"), dtype FPD_F32 or FPD_BF16; conv weights are
+ *     K,R,S,C (the reference's OIHW tensor stored channels-last); statistics are fp64.
+ */
+#ifndef FPD_AMD_H
+#define FPD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fpd_stream_t; /* hipStream_t */
+
+enum { FPD_F32 = 0, FPD_BF16 = 1 };
+enum { FPD_BN_NONE = 0, FPD_BN_TRAIN = 1, FPD_BN_EVAL = 2 };
+enum { FPD_EPI_PLAIN = 0, FPD_EPI_BNRELU_BWD = 1 };
+enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1 };
+
+/* nn.BatchNorm2d(momentum=0.1) (hourglass.py:18-25,118,162) applied on the fly while a consumer
+ * loads the tensor: a = relu?(x*scale+shift).  TRAIN: scale/shift derive from the batch
+ * statistics `stats` = {sum[C], sumsq[C]} accumulated by the tensor's producer; EVAL: from the
+ * running estimates. */
+typedef struct {
+    int32_t mode;          /* FPD_BN_* */
+    int32_t relu;          /* apply ReLU after the affine (hourglass.py:28) */
+    float eps;
+    int32_t _pad;
+    const double* stats;   /* TRAIN: [2][C] sum, sum of squares over N*H*W */
+    const float* gamma;    /* [C] */
+    const float* beta;     /* [C] */
+    const float* running_mean; /* EVAL: [C] */
+    const float* running_var;  /* EVAL: [C] */
+} fpd_bn_t;
+
+/* nn.Conv2d forward as an implicit GEMM (hourglass.py:20,23,27,116,135-137,143-145,163), with
+ * the preceding BN+ReLU fused on the input, and bias / residual add (hourglass.py:50,189) /
+ * batch statistics of the result (for the next train-mode BN) fused on the output.
+ * The same kernel computes the data gradient of a stride-1 conv when given the flipped,
+ * IO-swapped weights; epi = FPD_EPI_BNRELU_BWD then masks the result with the forward ReLU of
+ * tensor `epi_x` and accumulates the two BN-backward sums {sum dz, sum dz*xhat} into epi_stats. */
+typedef struct {
+    int32_t N, H, W, C;    /* input  [N,H,W,C] */
+    int32_t K, R, S;       /* output channels, filter height/width */
+    int32_t stride, pad;
+    int32_t P, Q;          /* output [N,P,Q,K] */
+    int32_t dtype;         /* FPD_F32 / FPD_BF16: x, w, residual, y, epi_x */
+    int32_t epi;           /* FPD_EPI_* */
+    int32_t _pad;
+    const void* x;
+    const void* w;         /* [K][R][S][C] */
+    const float* bias;     /* [K] or NULL */
+    const void* residual;  /* [N,P,Q,K] or NULL (may alias y) */
+    void* y;
+    double* out_stats;     /* [2][K] += {sum y, sum y^2} or NULL */
+    fpd_bn_t bn;           /* prologue on x (mode NONE = raw x) */
+    const void* epi_x;     /* BNRELU_BWD: forward tensor normalised by epi_bn, [N,P,Q,K] */
+    fpd_bn_t epi_bn;       /* BNRELU_BWD: its (train-mode) BN */
+    double* epi_stats;     /* BNRELU_BWD: [2][K] += {sum dz, sum dz*xhat} */
+} fpd_conv_t;
+
+/* Weight + bias gradient of the same conv (autograd of hourglass.py convs): dw[K][R][S][C] +=
+ * sum_pixels dy * a(x), dbias[K] += sum_pixels dy.  fp32 atomics; caller zeroes dw/dbias. */
+typedef struct {
+    int32_t N, H, W, C, K, R, S, stride, pad, P, Q, dtype;
+    const void* x;         /* forward input (pre-BN) */
+    const void* dy;        /* [N,P,Q,K] */
+    float* dw;             /* [K][R][S][C] fp32 */
+    float* dbias;          /* [K] or NULL */
+    fpd_bn_t bn;           /* forward prologue, recomputed */
+} fpd_wgrad_t;
+
+/* Stem: Conv2d(3, K, 7, stride 2, pad 3) (hourglass.py:116,172) reading the fp32 NCHW image. */
+typedef struct {
+    int32_t N, H, W, K, P, Q, dtype, _pad;
+    const float* x;        /* [N,3,H,W] fp32 NCHW */
+    const float* w;        /* [K][7][7][3] fp32 */
+    const float* bias;     /* [K] */
+    void* y;               /* [N,P,Q,K] */
+    double* out_stats;     /* [2][K] or NULL */
+    const void* dy;        /* wgrad: [N,P,Q,K] */
+    float* dw;             /* wgrad: [K][7][7][3] */
+    float* dbias;          /* wgrad: [K] */
+} fpd_stem_t;
+
+/* Elementwise / pooling ops on NHWC tensors.  `op` selects the function:
+ *  BNRELU_FWD   y = relu(bn(x)); out_stats += stats(y)                  (hourglass.py:173-174)
+ *  BNRELU_BWD_R dz = dy * (yfwd > 0) -> y ; bstats += {sum dz, sum dz*xhat(x)}
+ *  BN_BWD_APPLY y = add + gamma*invstd*(dz - s1/n - xhat(x)*s2/n)       (BatchNorm backward; dz in `dy`)
+ *  MAXPOOL_FWD  y = maxpool2x2(x); out_stats += stats(y)               (hourglass.py:82,177)
+ *  MAXPOOL_BWD  y = add + (x is the first max of its window ? dy : 0)
+ *  UPADD_FWD    y = x + nearest_up2(x2); out_stats += stats(y)         (hourglass.py:90-91)
+ *  SUMPOOL      y = add + sum2x2(x)                                    (Upsample backward)
+ *  ADD          y = x + x2
+ */
+enum {
+    FPD_EW_BNRELU_FWD = 0, FPD_EW_BNRELU_BWD_R = 1, FPD_EW_BN_BWD_APPLY = 2, FPD_EW_MAXPOOL_FWD = 3,
+    FPD_EW_MAXPOOL_BWD = 4, FPD_EW_UPADD_FWD = 5, FPD_EW_SUMPOOL = 6, FPD_EW_ADD = 7
+};
+typedef struct {
+    int32_t op, dtype;
+    int32_t N, H, W, C;    /* shape of the LARGER spatial tensor involved (pool input / up output) */
+    const void* x;         /* see table */
+    const void* x2;
+    const void* dy;
+    const void* add;       /* optional accumulate source (may alias y) */
+    void* y;
+    double* out_stats;     /* [2][C] or NULL */
+    double* bstats;        /* BN-backward sums [2][C] */
+    float* dgamma;         /* BN_BWD_APPLY: optional [C] <- sum dz*xhat (grad of BN weight) */
+    float* dbeta;          /* BN_BWD_APPLY: optional [C] <- sum dz      (grad of BN bias) */
+    fpd_bn_t bn;
+} fpd_ew_t;
+
+/* JointsMSELoss pose + KD over all stacks, forward and backward in one pass
+ * (lib/core/loss.py:21-39 called 2*S times at lib/core/function.py:128-134):
+ *   pose = sum_s 0.5/(B*J*hw) sum w^2 (p_s-g)^2 ; kd likewise against the teacher map t;
+ *   dout_s = w^2 [(1-alpha)(p_s-g) + alpha (p_s-t)] / (B*J*hw). */
+#define FPD_MAX_STACKS 8
+typedef struct {
+    int32_t B, J, H, W, S, dtype;
+    int32_t target_nchw;   /* 1: target is [B,J,H,W] (reference loader layout); 0: [B,H,W,J] */
+    float alpha;
+    const void* out[FPD_MAX_STACKS];  /* student maps, NHWC [B,H,W,J] */
+    void* dout[FPD_MAX_STACKS];       /* gradients, same layout (NULL = forward only) */
+    const void* teacher;   /* NHWC [B,H,W,J] in dtype */
+    const float* target;   /* fp32 */
+    const float* weight;   /* [B,J] fp32 */
+    double* losses;        /* [2] += {pose, kd}; caller zeroes */
+    float grad_scale;      /* extra factor on dout (1/world for DP averaging), normally 1 */
+    int32_t _pad;
+} fpd_loss_t;
+
+/* torch.optim.Adam(lr) step over one flat fp32 arena (lib/utils/utils.py:69-73), optionally
+ * emitting the bf16 working copy of the parameters. */
+typedef struct {
+    int64_t n;
+    float* param; const float* grad; float* m; float* v;
+    void* param_lp;        /* optional bf16 copy [n] */
+    float lr, beta1, beta2, eps;
+    float bias_corr1, bias_corr2;   /* 1-beta^t */
+    float grad_scale;      /* multiply grads first (1/world_size) */
+    int32_t _pad;
+    const float* lr_dev;   /* optional: read lr from device memory (graph-replay safe) */
+    int64_t* step_dev;     /* optional: device step counter t (bias corrections use t+1; incremented after) */
+} fpd_adam_t;
+
+/* Per-conv working copies of the weights: cast to `dtype` in K,R,S,C order (forward operand)
+ * and the flipped, IO-swapped C,R,S,K copy (data-gradient operand).  One launch for a table. */
+typedef struct {
+    const float* w;        /* master [K][R][S][C] fp32 */
+    void* w_fwd;           /* [K][R][S][C] dtype, or NULL */
+    void* w_bwd;           /* [C][R][S][K] dtype with r,s flipped, or NULL */
+    int32_t K, R, S, C;
+} fpd_wprep_entry_t;
+
+/* Running-statistics update of train-mode BNs after a forward (torch: momentum 0.1, unbiased
+ * variance; hourglass.py:10).  One launch for a table. */
+typedef struct {
+    const double* stats;   /* [2][C] */
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    double count; float momentum; int32_t C;
+} fpd_bnupd_entry_t;
+
+/* ---- single-op entry points (asynchronous on `stream`) ---- */
+int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream);
+int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
+int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream);
+int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream);
+int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream);
+int fpd_loss(const fpd_loss_t* a, fpd_stream_t stream);
+int fpd_adam(const fpd_adam_t* a, fpd_stream_t stream);
+int fpd_weight_prep(const fpd_wprep_entry_t* table_dev, int32_t n_entries, int64_t max_elems, int32_t dtype,
+                    fpd_stream_t stream);
+int fpd_bn_update_running(const fpd_bnupd_entry_t* table_dev, int32_t n_entries, fpd_stream_t stream);
+int fpd_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, fpd_stream_t stream);
+/* [N,C,H,W] fp32 <-> [N,H,W,C] dtype layout changes at the module boundary */
+int fpd_nchw_to_nhwc(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype,
+                     fpd_stream_t stream);
+int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype,
+                     fpd_stream_t stream);
+
+/* ---- execution plan: a recorded list of the ops above, replayed with one call ---- */
+enum {
+    FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
+    FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9
+};
+typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
+typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;
+
+typedef struct fpd_plan fpd_plan;
+fpd_plan* fpd_plan_create(void);
+void fpd_plan_destroy(fpd_plan* p);
+/* appends one op (args are copied); returns its index or <0 */
+int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t args_bytes);
+int fpd_plan_size(const fpd_plan* p);
+/* launch ops [begin,end) on stream */
+int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
+/* capture ops [begin,end) into a hipGraph once, then replay it (graph id returned by capture) */
+int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
+int fpd_plan_replay(fpd_plan* p, int32_t graph_id, fpd_stream_t stream);
+
+/* ---- misc ---- */
+const char* fpd_last_error(void);
+int fpd_set_backend(int32_t backend);         /* FPD_BACKEND_*; returns previous */
+int fpd_abi_sizeof(const char* struct_name);  /* sizeof of a struct above, -1 if unknown */
+int fpd_abi_version(void);
+/* in-stream timing helpers (HIP events on `stream`): returns elapsed ms of [start,stop) */
+void* fpd_event_create(void);
+int fpd_event_record(void* ev, fpd_stream_t stream);
+float fpd_event_elapsed_ms(void* start, void* stop); /* synchronises on stop */
+void fpd_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPD_AMD_H */

@@ -1,0 +1,248 @@
+"""CPU interpreter of the product's op list (test infrastructure -- never imported by the product).
+
+Executes the IR built by `fast-human-pose-estimation.pytorch_amd/graph.py` with plain torch CPU ops
+over the SAME arenas/offsets the GPU executor uses.  Two purposes:
+  1. validate the host logic (graph wiring, fused-BN algebra, reverse-mode construction, memory
+     planning/aliasing) against the reference-pinned oracle without a GPU;
+  2. serve as the per-op specification the HIP kernels are compared with in the `-m gpu` tests.
+Each op's semantics restate include/fpd_amd.h; the arithmetic they replace is the torch.nn graph of
+/root/reference/lib/models/hourglass.py and its autograd.
+"""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+
+
+class Arenas:
+    """name -> flat CPU tensor; `view(buf)` returns the tensor region of a graph.Buf."""
+
+    def __init__(self, sizes, act_dtype=torch.float32):
+        self.t = {}
+        self.act_dtype = act_dtype
+        for name, n in sizes.items():
+            if name in ('act', 'wlp'):
+                dt = act_dtype
+            elif name in ('stats', 'losses'):
+                dt = torch.float64
+            elif name == 'nbt':
+                dt = torch.int64
+            else:
+                dt = torch.float32
+            self.t[name] = torch.zeros(max(int(n), 1), dtype=dt)
+
+    def view(self, buf):
+        return self.t[buf.arena][buf.off:buf.off + buf.numel].view(buf.shape)
+
+
+def _bn_coef(A, bn):
+    gamma, beta = A.view(bn.gamma).double(), A.view(bn.beta).double()
+    if bn.mode == 'train':
+        st = A.view(bn.stats)
+        mean = st[0] / bn.count
+        var = (st[1] / bn.count - mean * mean).clamp_min(0)
+    else:
+        mean, var = A.view(bn.rmean).double(), A.view(bn.rvar).double()
+    invstd = 1.0 / torch.sqrt(var + EPS)
+    scale = (gamma * invstd).float()
+    shift = (beta - mean * gamma * invstd).float()
+    return scale, shift, mean.float(), invstd.float()
+
+
+def _act(A, a):
+    return A.view(a.buf).float()
+
+
+def _store(A, a, val):
+    A.view(a.buf).copy_(val.to(A.act_dtype))
+
+
+def _rnd(A, v):
+    return v.to(A.act_dtype).float()
+
+
+def _stats_add(A, buf, v):          # v: [N,H,W,C] fp32 already rounded to storage precision
+    st = A.view(buf)
+    vd = v.double()
+    st[0] += vd.sum((0, 1, 2))
+    st[1] += (vd * vd).sum((0, 1, 2))
+
+
+def _prologue(A, x, bn):
+    if bn is None:
+        return x
+    scale, shift, _, _ = _bn_coef(A, bn)
+    y = torch.addcmul(shift, x, scale)
+    if bn.relu:
+        y = y.clamp_min(0)
+    return _rnd(A, y)
+
+
+def run_conv(A, op):
+    n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
+    x = _prologue(A, _act(A, op.x), op.bn)
+    wt = A.view(op.w).float()                     # [K,R,S,C]
+    y = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if op.bias is not None:
+        y = y + A.view(op.bias)
+    if op.residual is not None:
+        y = y + _act(A, op.residual)
+    if op.epi == 'bnrelu_bwd':
+        xv = _act(A, op.epi_x)
+        scale, shift, mean, invstd = _bn_coef(A, op.epi_bn)
+        z = torch.addcmul(shift, xv, scale)
+        if op.epi_bn.relu:
+            y = torch.where(z > 0, y, torch.zeros_like(y))
+        yr = _rnd(A, y).double()
+        st = A.view(op.epi_stats)
+        st[0] += yr.sum((0, 1, 2))
+        st[1] += (yr * ((xv - mean) * invstd).double()).sum((0, 1, 2))
+    elif op.out_stats is not None:
+        _stats_add(A, op.out_stats, _rnd(A, y))
+    _store(A, op.y, y)
+
+
+def run_wgrad(A, op):
+    n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
+    x = _prologue(A, _act(A, op.x), op.bn).permute(0, 3, 1, 2)
+    dy = _act(A, op.dy).permute(0, 3, 1, 2)
+    dw = torch.nn.grad.conv2d_weight(x, (K, C, R, S), dy, stride=stride, padding=pad)   # [K,C,R,S]
+    A.view(op.dw).add_(dw.permute(0, 2, 3, 1))
+    if op.dbias is not None:
+        A.view(op.dbias).add_(dy.sum((0, 2, 3)))
+
+
+def run_stem_fwd(A, op):
+    img = A.view(op.image)
+    wt = A.view(op.w).permute(0, 3, 1, 2)         # [K,7,7,3] -> [K,3,7,7]
+    y = F.conv2d(img, wt, A.view(op.bias), stride=2, padding=3).permute(0, 2, 3, 1)
+    y = _rnd(A, y)
+    if op.out_stats is not None:
+        _stats_add(A, op.out_stats, y)
+    _store(A, op.y, y)
+
+
+def run_stem_wgrad(A, op):
+    img = A.view(op.image)
+    dy = _act(A, op.dy).permute(0, 3, 1, 2)
+    K = dy.shape[1]
+    dw = torch.nn.grad.conv2d_weight(img, (K, 3, 7, 7), dy, stride=2, padding=3)
+    A.view(op.dw).add_(dw.permute(0, 2, 3, 1))
+    A.view(op.dbias).add_(dy.sum((0, 2, 3)))
+
+
+def run_ew(A, op):
+    name = op.op
+    if name == 'bnrelu_fwd':
+        y = _prologue(A, _act(A, op.x), op.bn)
+        if op.out_stats is not None:
+            _stats_add(A, op.out_stats, y)
+        _store(A, op.y, y)
+    elif name == 'bnrelu_bwd_r':
+        x, dy = _act(A, op.x), _act(A, op.dy)
+        scale, shift, mean, invstd = _bn_coef(A, op.bn)
+        z = torch.addcmul(shift, x, scale)
+        dz = torch.where(z > 0, dy, torch.zeros_like(dy)) if op.bn.relu else dy
+        dzr = _rnd(A, dz).double()
+        st = A.view(op.bstats)
+        st[0] += dzr.sum((0, 1, 2))
+        st[1] += (dzr * ((x - mean) * invstd).double()).sum((0, 1, 2))
+        _store(A, op.y, dz)
+    elif name == 'bn_bwd_apply':
+        x, dz = _act(A, op.x), _act(A, op.dy)
+        _, _, mean, invstd = _bn_coef(A, op.bn)
+        st = A.view(op.bstats)
+        m1, m2 = (st[0] / op.bn.count).float(), (st[1] / op.bn.count).float()
+        g = A.view(op.bn.gamma)
+        out = (g * invstd) * (dz - m1 - ((x - mean) * invstd) * m2)
+        if op.add is not None:
+            out = out + _act(A, op.add)
+        if op.dgamma is not None:
+            A.view(op.dgamma).copy_(st[1].float())
+        if op.dbeta is not None:
+            A.view(op.dbeta).copy_(st[0].float())
+        _store(A, op.y, out)
+    elif name == 'maxpool_fwd':
+        y = F.max_pool2d(_act(A, op.x).permute(0, 3, 1, 2), 2, stride=2).permute(0, 2, 3, 1)
+        if op.out_stats is not None:
+            _stats_add(A, op.out_stats, y)
+        _store(A, op.y, y)
+    elif name == 'maxpool_bwd':
+        x = _act(A, op.x).permute(0, 3, 1, 2)
+        _, idx = F.max_pool2d(x, 2, stride=2, return_indices=True)
+        dy = _act(A, op.dy).permute(0, 3, 1, 2)
+        dx = F.max_unpool2d(dy, idx, 2, stride=2, output_size=x.shape[2:]).permute(0, 2, 3, 1)
+        if op.add is not None:
+            dx = dx + _act(A, op.add)
+        _store(A, op.y, dx)
+    elif name == 'upadd_fwd':
+        up = F.interpolate(_act(A, op.x2).permute(0, 3, 1, 2), scale_factor=2, mode='nearest').permute(0, 2, 3, 1)
+        y = _rnd(A, _act(A, op.x) + up)
+        if op.out_stats is not None:
+            _stats_add(A, op.out_stats, y)
+        _store(A, op.y, y)
+    elif name == 'sumpool':
+        y = 4.0 * F.avg_pool2d(_act(A, op.x).permute(0, 3, 1, 2), 2, stride=2).permute(0, 2, 3, 1)
+        if op.add is not None:
+            y = y + _act(A, op.add)
+        _store(A, op.y, y)
+    elif name == 'add':
+        _store(A, op.y, _act(A, op.x) + _act(A, op.x2))
+    else:
+        raise AssertionError(name)
+
+
+def run_bnupd(A, op, momentum=0.1):
+    for bn in op.bns:
+        st = A.view(bn.stats)
+        mean = st[0] / bn.count
+        var = (st[1] / bn.count - mean * mean).clamp_min(0)
+        unb = var * bn.count / (bn.count - 1) if bn.count > 1 else var
+        rm, rv = A.view(bn.rmean), A.view(bn.rvar)
+        rm.copy_(((1 - momentum) * rm.double() + momentum * mean).float())
+        rv.copy_(((1 - momentum) * rv.double() + momentum * unb).float())
+        A.view(bn.nbt).add_(1)
+
+
+def run_loss(A, op):
+    """include/fpd_amd.h fpd_loss_t: losses += {pose, kd}; dout_s = gs*w^2[(1-a)(p-g)+a(p-t)]/cnt."""
+    tgt = A.t['target'].view(op.target_shape)                   # [B,J,H,W] fp32
+    wgt = A.t['weight'].view(op.B, op.J)
+    t = _act_any(A, op.teacher)
+    cnt = float(tgt.numel())
+    g = tgt.permute(0, 2, 3, 1)
+    w2 = (wgt * wgt)[:, None, None, :]
+    losses = A.t['losses']
+    for s, o in enumerate(op.outs):
+        p = _act(A, o)
+        dg, dt = p - g, p - t
+        losses[0] += 0.5 * (w2 * dg * dg).double().sum() / cnt
+        losses[1] += 0.5 * (w2 * dt * dt).double().sum() / cnt
+        if op.douts is not None:
+            _store(A, op.douts[s], op.grad_scale * w2 * ((1 - op.alpha) * dg + op.alpha * dt) / cnt)
+
+
+def _act_any(A, a):
+    return a if isinstance(a, torch.Tensor) else _act(A, a)
+
+
+def run_wprep(A, op):
+    for e in op.entries:
+        w = A.view(e['w'])
+        if e.get('w_fwd') is not None:
+            A.view(e['w_fwd']).copy_(w.to(A.act_dtype))
+        if e.get('w_bwd') is not None:
+            A.view(e['w_bwd']).copy_(w.flip(1, 2).permute(3, 1, 2, 0).to(A.act_dtype))
+
+
+RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgrad': run_stem_wgrad, 'ew': run_ew,
+       'bnupd': run_bnupd, 'loss': run_loss, 'wprep': run_wprep}
+
+
+def run(A, ops):
+    with torch.no_grad():
+        for op in ops:
+            if op.kind == 'memset':
+                A.t[op.arena][op.off:op.off + op.n].zero_()
+            else:
+                RUN[op.kind](A, op)

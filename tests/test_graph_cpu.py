@@ -1,0 +1,106 @@
+"""Host logic of the product (graph wiring, fused-BN algebra, reverse mode, memory planning) executed by the
+CPU interpreter and compared with the reference outputs in tests/golden."""
+import numpy as np
+import pytest
+import torch
+
+from fpd_amd import graph as G
+from oracle import hourglass_ref, plan_interp as PI
+from tests import _cases, _interp_util as U
+
+
+def build(name, train, which='s', wlp_is_master=True):
+    c = _cases.CONFIGS[name]
+    feats, stacks = c[which]
+    table = G.ParamTable(hourglass_ref.hourglass_keys(feats, stacks, c['joints']))
+    g = G.HourglassGraph(table, feats, stacks, c['joints'], c['batch'], c['image'][1], c['image'][0], train,
+                         wlp_is_master=wlp_is_master)
+    return c, table, g
+
+
+@pytest.mark.parametrize('name', ['tiny', 'cfg1'])
+def test_teacher_eval_forward(name):
+    c, table, g = build(name, train=False, which='t')
+    gold = _cases.load_golden(name)
+    _, t_sd = _cases.state_dicts(name, gold)
+    act = G.plan_memory(g.fwd)
+    A = U.make_arenas(g, table, act)
+    U.load_params(A, table, t_sd)
+    x, _, _ = _cases.batch(name)
+    A.t['image'].copy_(x.reshape(-1))
+    PI.run(A, g.fwd)
+    out = A.view(g.outputs[-1].buf).permute(0, 3, 1, 2)
+    _cases.assert_parity(out.numpy(), gold['toutput'], _cases.truth64(name)['toutput'].numpy(), 'teacher map')
+    # liveness-based planning must beat "one buffer per tensor" by a wide margin for inference
+    total = sum(o.y.numel for o in g.fwd if hasattr(o, 'y'))
+    assert act < 0.25 * total
+
+
+@pytest.mark.parametrize('name,master', [('tiny', True), ('tiny', False), ('cfg1', True)])
+def test_student_train_step(name, master):
+    c, table, g = build(name, train=True, which='s', wlp_is_master=master)
+    gold = _cases.load_golden(name)
+    s_sd, _ = _cases.state_dicts(name, gold)
+    x, tg, tw = _cases.batch(name)
+    B, J = c['batch'], c['joints']
+    hh, hw = c['heat'][1], c['heat'][0]
+    teacher = torch.from_numpy(gold['toutput']).permute(0, 2, 3, 1).contiguous()
+    loss = G.Op('loss', outs=g.outputs, douts=g.out_grads, teacher=teacher, alpha=0.5, grad_scale=1.0, B=B, J=J,
+                target_shape=(B, J, hh, hw), extra_in=list(g.outputs), extra_out=list(g.out_grads))
+    ops = g.fwd + [loss] + g.bwd
+    act = G.plan_memory(ops)
+    A = U.make_arenas(g, table, act, extra={'target': tg.numel(), 'weight': tw.numel()})
+    U.load_params(A, table, s_sd)
+    A.t['image'].copy_(x.reshape(-1))
+    A.t['target'].copy_(tg.reshape(-1))
+    A.t['weight'].copy_(tw.reshape(-1))
+    PI.run(A, [U.wprep_op(g, table)] + ops)
+    tr = _cases.truth64(name)
+    for i, o in enumerate(g.outputs):
+        _cases.assert_parity(A.view(o.buf).permute(0, 3, 1, 2).numpy(), gold['output%d' % i],
+                             tr['outputs'][i].numpy(), 'student map %d' % i)
+    # the loss op was fed the reference's fp32 teacher map, so compare with the reference's fp32 losses
+    assert abs(A.t['losses'][0].item() - float(gold['pose'])) < 1e-5
+    assert abs(A.t['losses'][1].item() - float(gold['kd'])) < 1e-5
+    flat = U.flat_grads_oihw(A, table)
+    stride = int(gold['grad_stride'])
+    names = [k for k in table.trainable_keys()]
+    t64 = torch.cat([tr['grads'][k].reshape(-1) for k in names])[::stride].numpy()
+    _cases.assert_parity(flat[::stride].numpy(), gold['grad_flat'], t64, 'student gradients', floor=2e-6, atol=1e-5)
+    for k in table.entries:
+        if 'running' in k:
+            np.testing.assert_allclose(A.view(table[k]).numpy(), gold['s_after/' + k], rtol=1e-4, atol=1e-5)
+        if k.endswith('num_batches_tracked'):
+            assert A.view(table[k]).item() == 1
+
+
+def test_memory_plan_no_live_overlap():
+    """No two simultaneously-live tensors may share bytes (checked independently of plan_memory's allocator)."""
+    c, table, g = build('tiny', train=True)
+    ops = g.fwd + g.bwd
+    G.plan_memory(ops)
+    first, last, acts = {}, {}, {}
+    for i, op in enumerate(ops):
+        for a in op.acts_in() + op.acts_out():
+            first.setdefault(id(a), i)
+            last[id(a)] = i
+            acts[id(a)] = a
+    items = sorted(acts.values(), key=lambda a: a.buf.off)
+    for i, a in enumerate(items):
+        for b in items[i + 1:]:
+            if b.buf.off >= a.buf.off + a.numel:
+                break
+            la = 10 ** 9 if a.persistent else last[id(a)]
+            lb = 10 ** 9 if b.persistent else last[id(b)]
+            assert la < first[id(b)] or lb < first[id(a)], (a.name, b.name)
+
+
+def test_param_table_layout():
+    keys = hourglass_ref.hourglass_keys(32, 2, 16)
+    t = G.ParamTable(keys)
+    assert t['conv1.weight'].shape == (8, 7, 7, 3)
+    assert t['layer1.0.conv2.weight'].shape == (8, 3, 3, 8)
+    offs = [(b.off, b.numel) for b in t.entries.values() if b.arena == 'param']
+    for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+        assert o1 + n1 <= o2 and o2 % 4 == 0
+    assert len(t.trainable_keys()) == sum(1 for k, _ in keys if 'running' not in k and 'tracked' not in k)
