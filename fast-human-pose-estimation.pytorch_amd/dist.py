@@ -1,0 +1,48 @@
+"""Data-parallel replicas: one process per GPU, student gradients summed with ONE RCCL all-reduce of the flat
+gradient arena per step (torch.distributed backend 'nccl' == RCCL over xGMI on ROCm).
+
+Replaces the reference's single-process nn.DataParallel (/root/reference/tools/fpd_train.py:143,173): no
+per-step parameter re-broadcast, no output gather; each rank runs the whole FPD step on its shard with
+per-replica BatchNorm statistics (the same semantics DataParallel has), the loss kernel scales gradients by
+1/world so the summed gradient is the gradient of the global-batch mean (equal shards).  The collective is
+issued asynchronously right after the backward and waited for only before Adam, i.e. it overlaps the NEXT
+step's teacher forward, which does not depend on the student weights (executor.FusedFPDStep.step)."""
+import torch
+
+
+def make_allreduce(dist, group=None):
+    """Returns hook(flat_grad) -> wait() for executor.FusedFPDStep.step(allreduce=...)."""
+    def hook(flat_grad):
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return work.wait            # makes the current stream wait for the collective; no host sync on NCCL/RCCL
+    return hook
+
+
+def broadcast_state(dist, model, src=0, group=None):
+    """Make every replica start from rank `src`'s parameters and BN buffers (flat arenas: 3 collectives)."""
+    for name in ('param', 'rstat', 'nbt'):
+        dist.broadcast(model._flat[name], src=src, group=group)
+
+
+def shard(batch_tensors, rank, world):
+    """Rank r takes samples [r*B/world, (r+1)*B/world) of each tensor -- DataParallel's dim-0 scatter
+    (tools/fpd_train.py:202: loader batch = BATCH_SIZE_PER_GPU * len(GPUS))."""
+    out = []
+    for t in batch_tensors:
+        n = t.shape[0]
+        assert n % world == 0, 'global batch %d not divisible by world size %d' % (n, world)
+        per = n // world
+        out.append(t[rank * per:(rank + 1) * per])
+    return out
+
+
+class DataParallelReplica(torch.nn.Module):
+    """`.module` / `.parameters()` / `.state_dict()` surface the reference scripts use on their DataParallel
+    wrapper (tools/fpd_train.py:279-294; state_dict keys carry the 'module.' prefix like the reference's)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)

@@ -1,0 +1,380 @@
+"""Device-side realisation of graph.py: arenas in HBM, lowering of the op list to the C ABI, native
+execution plans (one C call or one hipGraph replay per phase), and the fused FPD train step.
+
+PyTorch is used here only as the HBM allocator, stream provider and RCCL front end
+(torch.distributed); every kernel that touches the data is in csrc/ (libfpd_amd.so).
+"""
+import ctypes as C
+
+import torch
+
+from . import graph as G
+from . import runtime as R
+
+_EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd_apply': R.EW_BN_BWD_APPLY,
+       'maxpool_fwd': R.EW_MAXPOOL_FWD, 'maxpool_bwd': R.EW_MAXPOOL_BWD, 'upadd_fwd': R.EW_UPADD_FWD,
+       'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD}
+_ARENA_DTYPE = {'param': torch.float32, 'grad': torch.float32, 'rstat': torch.float32, 'nbt': torch.int64,
+                'stats': torch.float64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
+                'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32}
+
+
+def act_torch_dtype(dtype):
+    return torch.bfloat16 if dtype == R.BF16 else torch.float32
+
+
+class Arenas:
+    """name -> flat device tensor.  Lookups fall through to `parent` (model-level arenas)."""
+
+    def __init__(self, device, dtype, parent=None):
+        self.device, self.dtype, self.parent = device, dtype, parent
+        self.t = {}
+
+    def alloc(self, name, n):
+        dt = _ARENA_DTYPE.get(name, act_torch_dtype(self.dtype))
+        self.t[name] = torch.zeros(max(int(n), 4), dtype=dt, device=self.device)
+        return self.t[name]
+
+    def tensor(self, name):
+        if name in self.t:
+            return self.t[name]
+        if self.parent is not None:
+            return self.parent.tensor(name)
+        raise KeyError(name)
+
+    def ptr(self, buf):
+        if buf is None:
+            return None
+        t = self.tensor(buf.arena)
+        return t.data_ptr() + buf.off * t.element_size()
+
+    def view(self, buf):
+        return self.tensor(buf.arena)[buf.off:buf.off + buf.numel].view(buf.shape)
+
+
+def _abuf(a):
+    return None if a is None else (a.buf if isinstance(a, G.Act) else a)
+
+
+class Lowering:
+    """IR op -> (native op code, ctypes struct)."""
+
+    def __init__(self, arenas, dtype):
+        self.A, self.dtype = arenas, dtype
+        self.keep = []          # device tables that must outlive the plan
+
+    def bn(self, bn):
+        s = R.BnT()
+        if bn is None:
+            s.mode = R.BN_NONE
+            return s
+        s.mode = R.BN_TRAIN if bn.mode == 'train' else R.BN_EVAL
+        s.relu = 1 if bn.relu else 0
+        s.eps = G.BN_EPS
+        s.stats = self.A.ptr(bn.stats) if bn.mode == 'train' else None
+        s.gamma, s.beta = self.A.ptr(bn.gamma), self.A.ptr(bn.beta)
+        s.running_mean, s.running_var = self.A.ptr(bn.rmean), self.A.ptr(bn.rvar)
+        return s
+
+    def conv(self, op):
+        s = R.ConvT()
+        (s.N, s.H, s.W, s.C, s.K, s.R, s.S, s.stride, s.pad, s.P, s.Q) = op.dims
+        s.dtype = self.dtype
+        s.epi = R.EPI_BNRELU_BWD if op.epi == 'bnrelu_bwd' else R.EPI_PLAIN
+        p = self.A.ptr
+        s.x, s.w, s.bias, s.residual, s.y = p(_abuf(op.x)), p(op.w), p(op.bias), p(_abuf(op.residual)), p(_abuf(op.y))
+        s.out_stats = p(op.out_stats)
+        s.bn = self.bn(op.bn)
+        s.epi_x, s.epi_bn, s.epi_stats = p(_abuf(op.epi_x)), self.bn(op.epi_bn), p(op.epi_stats)
+        return R.OP_CONV, s
+
+    def wgrad(self, op):
+        s = R.WgradT()
+        (s.N, s.H, s.W, s.C, s.K, s.R, s.S, s.stride, s.pad, s.P, s.Q) = op.dims
+        s.dtype = self.dtype
+        p = self.A.ptr
+        s.x, s.dy, s.dw, s.dbias = p(_abuf(op.x)), p(_abuf(op.dy)), p(op.dw), p(op.dbias)
+        s.bn = self.bn(op.bn)
+        return R.OP_WGRAD, s
+
+    def stem(self, op):
+        s = R.StemT()
+        (s.N, s.H, s.W, s.K, s.P, s.Q) = op.dims
+        s.dtype = self.dtype
+        p = self.A.ptr
+        s.x = p(op.image)
+        if op.kind == 'stem_fwd':
+            s.w, s.bias, s.y, s.out_stats = p(op.w), p(op.bias), p(_abuf(op.y)), p(op.out_stats)
+            return R.OP_STEM_FWD, s
+        s.dy, s.dw, s.dbias = p(_abuf(op.dy)), p(op.dw), p(op.dbias)
+        return R.OP_STEM_WGRAD, s
+
+    def ew(self, op):
+        s = R.EwT()
+        s.op, s.dtype = _EW[op.op], self.dtype
+        (s.N, s.H, s.W, s.C) = op.dims
+        p = self.A.ptr
+        s.x, s.x2, s.dy, s.add, s.y = p(_abuf(op.x)), p(_abuf(op.x2)), p(_abuf(op.dy)), p(_abuf(op.add)), p(_abuf(op.y))
+        s.out_stats, s.bstats, s.dgamma, s.dbeta = p(op.out_stats), p(op.bstats), p(op.dgamma), p(op.dbeta)
+        s.bn = self.bn(op.bn)
+        return R.OP_EW, s
+
+    def _table(self, entries, cls):
+        arr = (cls * len(entries))(*entries)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.A.device)
+        self.keep.append(raw)
+        return raw.data_ptr()
+
+    def bnupd(self, op):
+        ents = []
+        for bn in op.bns:
+            e = R.BnupdEntryT()
+            e.stats, e.running_mean, e.running_var = self.A.ptr(bn.stats), self.A.ptr(bn.rmean), self.A.ptr(bn.rvar)
+            e.num_batches_tracked = self.A.ptr(bn.nbt)
+            e.count, e.momentum, e.C = float(bn.count), G.BN_MOMENTUM, bn.C
+            ents.append(e)
+        s = R.TableT()
+        s.table, s.n, s.dtype, s.max_elems = self._table(ents, R.BnupdEntryT), len(ents), self.dtype, 0
+        return R.OP_BNUPD, s
+
+    def wprep(self, entries):
+        ents, mx = [], 0
+        for w, wf, wb in entries:
+            e = R.WprepEntryT()
+            e.w, e.w_fwd, e.w_bwd = self.A.ptr(w), self.A.ptr(wf), self.A.ptr(wb)
+            (e.K, e.R, e.S, e.C) = w.shape
+            mx = max(mx, w.numel)
+            ents.append(e)
+        s = R.TableT()
+        s.table, s.n, s.dtype, s.max_elems = self._table(ents, R.WprepEntryT), len(ents), self.dtype, mx
+        return R.OP_WPREP, s
+
+    def memset(self, arena_name, off=0, n=None):
+        t = self.A.tensor(arena_name)
+        n = t.numel() - off if n is None else n
+        s = R.MemsetT()
+        s.ptr, s.bytes = t.data_ptr() + off * t.element_size(), n * t.element_size()
+        return R.OP_MEMSET, s
+
+    def op(self, op):
+        return {'conv': self.conv, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
+                'bnupd': self.bnupd}[op.kind](op)
+
+
+class ModelState:
+    """Flat HBM arenas of one model's state_dict (see graph.ParamTable)."""
+
+    def __init__(self, table, device, dtype):
+        self.table, self.device, self.dtype = table, device, dtype
+        self.A = Arenas(device, dtype)
+        for name in ('param', 'rstat', 'nbt'):
+            self.A.alloc(name, table.sizes[name])
+        self.A.alloc('grad', table.sizes['param'])
+
+
+class GraphInstance:
+    """One HourglassGraph realised on the device: activation/statistics/working-weight arenas + native plan.
+
+    Plan ranges (self.rng): 'prep' (zero statistics, refresh working weight copies), 'fwd', and for training
+    graphs 'bwd' (zero parameter gradients, backward ops).  `extra_ops` (e.g. the fused loss) can be spliced
+    between fwd and bwd by the trainer before finalize()."""
+
+    def __init__(self, state, cfg, batch, height, width, train, image=None):
+        self.state, self.train = state, train
+        self.dtype = state.dtype
+        self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
+                                  num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32))
+        self.A = Arenas(state.device, self.dtype, parent=state.A)
+        self.low = Lowering(self.A, self.dtype)
+        self.plan = R.Plan()
+        self.rng = {}
+        self._image_ext = image
+        self._finalized = False
+        self.mid_ops = []          # IR ops between fwd and bwd (loss)
+        self.mid_native = []       # callables adding native ops for the mid section
+
+    def finalize(self):
+        g = self.g
+        ops = g.fwd + self.mid_ops + g.bwd
+        act = G.plan_memory(ops)
+        self.act_elems = act
+        self.A.alloc('act', act)
+        self.A.alloc('stats', g.stats_size)
+        self.A.alloc('wlp', g.wlp_size)
+        if self._image_ext is not None:
+            self.A.t['image'] = self._image_ext
+        else:
+            self.A.alloc('image', g.N * 3 * g.H * g.W)
+        p = self.plan
+        b = len(p)
+        p.add(*self.low.memset('stats'))
+        entries = []
+        for k in self.state.table.conv_keys():
+            if k == 'conv1.weight':
+                continue
+            wf, wb = g.wfwd.get(k), g.wbwd.get(k)
+            if wf is not None or wb is not None:
+                entries.append((self.state.table[k], wf, wb))
+        if entries:
+            p.add(*self.low.wprep(entries))
+        self.rng['prep'] = (b, len(p))
+        b = len(p)
+        for op in g.fwd:
+            p.add(*self.low.op(op))
+        self.rng['fwd'] = (b, len(p))
+        b = len(p)
+        for fn in self.mid_native:
+            fn(p)
+        self.rng['mid'] = (b, len(p))
+        if self.train:
+            b = len(p)
+            p.add(*self.low.memset('grad'))
+            for op in g.bwd:
+                p.add(*self.low.op(op))
+            self.rng['bwd'] = (b, len(p))
+        self._finalized = True
+        return self
+
+    def run(self, name, stream=None):
+        b, e = self.rng[name]
+        self.plan.run(b, e, stream)
+
+    def image(self):
+        return self.A.tensor('image').view(self.g.N, 3, self.g.H, self.g.W)
+
+    def calibrate_running_stats(self):
+        """After one train-mode forward: overwrite every BN's running estimates with this batch's statistics
+        (unbiased variance).  Used to give random-init synthetic teachers sane eval-mode statistics
+        (SURVEY.md section 8(d)); not part of the train step."""
+        assert self.train
+        torch.cuda.synchronize()
+        for bn in self.g.bns:
+            st = self.A.view(bn.stats)
+            mean = st[0] / bn.count
+            var = (st[1] / bn.count - mean * mean).clamp_min(0) * (bn.count / max(bn.count - 1, 1))
+            self.A.view(bn.rmean).copy_(mean.float())
+            self.A.view(bn.rvar).copy_(var.float())
+
+    def output_view(self, i):
+        return self.A.view(self.g.outputs[i].buf)          # NHWC in act dtype
+
+    def out_grad_view(self, i):
+        return self.A.view(self.g.out_grads[i].buf)
+
+
+class FusedFPDStep:
+    """The fused FPD iteration (lib/core/function.py:119-147 of the reference) on one GPU:
+         teacher forward (eval BN) -> student forward (train BN) -> fused pose+KD loss fwd/bwd
+         -> student backward -> [RCCL all-reduce of the flat gradient] -> flat Adam.
+    No host synchronisation inside; losses are read back only when asked for."""
+
+    def __init__(self, student_state, student_cfg, teacher_state, teacher_cfg, batch, height, width, alpha,
+                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1):
+        dev = student_state.device
+        self.dtype = student_state.dtype
+        self.alpha, self.world_size = alpha, world_size
+        self.B, self.J = batch, student_cfg['J']
+        # teacher first: it owns the image buffer; its last-stack map is read in place by the loss kernel
+        self.teacher = None
+        image = None
+        if teacher_state is not None:
+            assert teacher_state.dtype == self.dtype
+            self.teacher = GraphInstance(teacher_state, teacher_cfg, batch, height, width, train=False).finalize()
+            self.teacher.run('prep')           # frozen weights: working copies are prepared once
+            image = self.teacher.A.tensor('image')
+        self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True, image=image)
+        g = self.student.g
+        self.hh, self.hw = g.outputs[0].shape[1:3]
+        A = self.student.A
+        A.alloc('target', self.B * self.J * self.hh * self.hw)
+        A.alloc('weight', self.B * self.J)
+        A.alloc('losses', 4)
+        self.student.mid_ops = [G.Op('loss', extra_in=list(g.outputs), extra_out=list(g.out_grads))]
+        self.student.mid_native = [self._add_loss]
+        self.student.finalize()
+        # optimizer state (torch.optim.Adam semantics, lib/utils/utils.py:69-73)
+        n = student_state.table.sizes['param']
+        self.n_param = n
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.betas, self.eps = betas, eps
+        a = R.AdamT()
+        a.n = n
+        pa = student_state.A
+        a.param, a.grad = pa.tensor('param').data_ptr(), pa.tensor('grad').data_ptr()
+        a.m, a.v = self.m.data_ptr(), self.v.data_ptr()
+        a.param_lp = None
+        a.lr, a.beta1, a.beta2, a.eps = lr, betas[0], betas[1], eps
+        a.bias_corr1 = a.bias_corr2 = 1.0
+        a.grad_scale = 1.0        # the loss kernel already folds 1/world_size into the gradient
+        a.lr_dev, a.step_dev = self.lr_dev.data_ptr(), self.step_dev.data_ptr()
+        self._adam_args = a
+        b = len(self.student.plan)
+        self.student.plan.add(R.OP_ADAM, a)
+        self.student.rng['adam'] = (b, len(self.student.plan))
+        self._dist_work = None
+
+    def _add_loss(self, plan):
+        A, g = self.student.A, self.student.g
+        plan.add(*self.student.low.memset('losses'))
+        s = R.LossT()
+        s.B, s.J, s.H, s.W, s.S, s.dtype = self.B, self.J, self.hh, self.hw, len(g.outputs), self.dtype
+        s.target_nchw, s.alpha = 1, self.alpha
+        for i, (o, d) in enumerate(zip(g.outputs, g.out_grads)):
+            s.out[i] = A.ptr(o.buf)
+            s.dout[i] = A.ptr(d.buf)
+        if self.teacher is not None:
+            s.teacher = self.teacher.A.ptr(self.teacher.g.outputs[-1].buf)
+        else:                                   # plain (non-KD) training: alpha must be 0, kd term reads the student map
+            s.teacher = A.ptr(g.outputs[-1].buf)
+        s.target, s.weight = A.tensor('target').data_ptr(), A.tensor('weight').data_ptr()
+        s.losses = A.tensor('losses').data_ptr()
+        s.grad_scale = 1.0 / self.world_size
+        plan.add(R.OP_LOSS, s)
+
+    # ---- data ----
+    def set_batch(self, inp, target, target_weight):
+        """Copy one loader batch (any device) into the step's fixed HBM buffers (async on the current stream)."""
+        self.student.image().copy_(inp, non_blocking=True)
+        self.student.A.tensor('target').view(target.shape).copy_(target, non_blocking=True)
+        self.student.A.tensor('weight').view(target_weight.shape).copy_(target_weight, non_blocking=True)
+
+    # ---- one iteration ----
+    def teacher_forward(self):
+        self.teacher.run('fwd')
+
+    def step(self, allreduce=None):
+        """One FPD iteration on the current stream.  `allreduce(flat_grad)` is the DP hook."""
+        s = self.student
+        if self.teacher is not None:
+            self.teacher_forward()
+        if self._dist_work is not None:        # previous step's gradient exchange overlapped the teacher forward
+            self._dist_work()
+            self._dist_work = None
+            s.run('adam')
+        s.run('prep')
+        s.run('fwd')
+        s.run('mid')
+        s.run('bwd')
+        if allreduce is not None:
+            self._dist_work = allreduce(self.student.state.A.tensor('grad'))
+        else:
+            s.run('adam')
+
+    def flush(self):
+        """Apply a pending (overlapped) optimizer update -- call after the last step()."""
+        if self._dist_work is not None:
+            self._dist_work()
+            self._dist_work = None
+            self.student.run('adam')
+
+    def losses(self):
+        """(pose, kd, total) of the last step -- synchronises."""
+        l = self.student.A.tensor('losses')[:2].cpu()
+        pose, kd = float(l[0]), float(l[1])
+        return pose, kd, (1 - self.alpha) * pose + self.alpha * kd
+
+    def set_lr(self, lr):
+        self.lr_dev.fill_(lr)

@@ -1,0 +1,411 @@
+"""Per-kernel parity on the MI355X: every HIP op, called through the C ABI, against its CPU specification
+(oracle/plan_interp.py) on seeded random inputs; both storage types, both HIP back ends (MFMA / direct).
+
+Tolerances (stated per test): fp32 build -- abs 2e-4 on O(1..10) values (accumulation-order noise only; the
+fp32 MFMA is an exact fp32 fma chain); bf16 build -- compared with the interpreter run with bf16 storage
+(same rounding points), abs/rel 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plan_interp as PI
+
+pytestmark = pytest.mark.gpu
+
+G = E = R = None
+
+
+def setup_module(module):
+    global G, E, R
+    from fpd_amd import executor, graph, runtime
+    G, E, R = graph, executor, runtime
+    R.lib()
+
+
+class Bench:
+    """Pair of identical arenas (CPU interpreter / GPU executor) with a bump allocator for test tensors."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.sizes = {}
+        self.fills = []
+
+    def buf(self, arena, shape, fill=None):
+        n = int(np.prod(shape)) if len(shape) else 1
+        off = self.sizes.get(arena, 0)
+        self.sizes[arena] = off + (n + 63) // 64 * 64
+        b = G.Buf(arena, off, shape, arena)
+        if fill is not None:
+            self.fills.append((b, fill))
+        return b
+
+    def act(self, shape, fill=None, name='t'):
+        a = G.Act(shape, name)
+        a.buf = self.buf('act', shape, fill)
+        return a
+
+    def realise(self):
+        tdt = torch.bfloat16 if self.dtype == 1 else torch.float32
+        self.cpu = PI.Arenas(self.sizes, tdt)
+        dev = torch.device('cuda:0')
+        self.gpu = E.Arenas(dev, self.dtype)
+        for name, n in self.sizes.items():
+            self.gpu.alloc(name, n)
+        for b, val in self.fills:
+            v = self.cpu.view(b)
+            v.copy_(val.reshape(v.shape).to(v.dtype))
+            self.gpu.view(b).copy_(v)
+        return self
+
+    def run(self, ops, backend):
+        PI.run(self.cpu, ops)
+        low = E.Lowering(self.gpu, self.dtype)
+        plan = R.Plan()
+        for op in ops:
+            if op.kind == 'wprep':
+                plan.add(*low.wprep([(e['w'], e.get('w_fwd'), e.get('w_bwd')) for e in op.entries]))
+            else:
+                plan.add(*low.op(op))
+        prev = R.set_backend(backend)
+        try:
+            plan.run(0, len(plan))
+            torch.cuda.synchronize()
+        finally:
+            R.set_backend(prev)
+
+    def compare(self, b, atol, rtol, label):
+        b = b.buf if isinstance(b, G.Act) else b
+        c = self.cpu.view(b).double()
+        g = self.gpu.view(b).cpu().double()
+        assert torch.isfinite(g).all(), label + ': non-finite values'
+        err = (c - g).abs()
+        tol = atol + rtol * c.abs()
+        bad = err > tol
+        assert not bad.any(), '%s: %d/%d mismatches, max err %.3e (ref max %.3e) first at %s' % (
+            label, int(bad.sum()), bad.numel(), float(err.max()), float(c.abs().max()),
+            [int(i) for i in torch.nonzero(bad)[0]])
+
+
+def rnd(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def make_bn(bench, gen, C, mode, name='bn', relu=True, stats_from=None):
+    gamma = bench.buf('param', (C,), 1 + 0.2 * rnd(gen, C))
+    beta = bench.buf('param', (C,), 0.2 * rnd(gen, C))
+    rmean = bench.buf('rstat', (C,), 0.1 * rnd(gen, C))
+    rvar = bench.buf('rstat', (C,), 1 + 0.2 * torch.rand(C, generator=gen))
+    nbt = bench.buf('nbt', ())
+    bn = G.BN(name, mode, C, gamma, beta, rmean, rvar, nbt, relu=relu)
+    return bn
+
+
+def tensor_stats(x):   # x [N,H,W,C] -> [2,C] fp64
+    xd = x.double()
+    return torch.stack([xd.sum((0, 1, 2)), (xd * xd).sum((0, 1, 2))])
+
+
+TOL = {0: dict(atol=2e-4, rtol=2e-4), 1: dict(atol=3e-2, rtol=3e-2)}
+BACKENDS = [0, 1]
+DTYPES = [0, 1]
+
+CONV_CASES = [
+    # N, H, W, C, K, R, pad, bn_mode, residual, stats
+    (2, 16, 16, 32, 64, 3, 1, 'train', True, True),
+    (2, 16, 16, 64, 32, 1, 0, 'eval', False, True),
+    (1, 5, 7, 16, 16, 3, 1, 'train', True, False),      # ragged M, smallest channel counts (score_/score convs)
+    (2, 8, 8, 128, 128, 3, 1, 'train', False, True),
+    (3, 8, 8, 128, 16, 1, 0, None, False, False),       # score conv: K = J = 16
+    (2, 4, 4, 16, 128, 1, 0, None, True, True),         # score_ conv: C = J = 16
+    (1, 64, 64, 64, 64, 3, 1, 'train', True, True),     # cfg-1 student 3x3 @64^2
+    (2, 8, 8, 256, 128, 1, 0, 'eval', False, False),    # teacher 1x1 256->128
+    (2, 8, 8, 48, 96, 3, 1, 'train', False, True),      # HRNet-W48 widths (not multiples of 32/64)
+]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward(case, dtype, backend):
+    N, H, W, C, K, Rr, pad, bn_mode, use_res, use_stats = case
+    gen = torch.Generator().manual_seed(17 + sum(v for v in case if isinstance(v, int) and not isinstance(v, bool)))
+    bt = Bench(dtype)
+    x_val = rnd(gen, N, H, W, C) + 0.3
+    x = bt.act((N, H, W, C), x_val, 'x')
+    w = bt.buf('wlp', (K, Rr, Rr, C), rnd(gen, K, Rr, Rr, C, scale=1.0 / np.sqrt(C * Rr * Rr)))
+    bias = bt.buf('param', (K,), 0.1 * rnd(gen, K))
+    P, Q = H + 2 * pad - Rr + 1, W + 2 * pad - Rr + 1
+    res = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K), 'res') if use_res else None
+    y = bt.act((N, P, Q, K), None, 'y')
+    bn = None
+    if bn_mode:
+        bn = make_bn(bt, gen, C, bn_mode)
+        bn.count = N * H * W
+        if bn_mode == 'train':
+            xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
+            bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+    ostats = bt.buf('stats', (2, K), torch.zeros(2, K, dtype=torch.float64)) if use_stats else None
+    op = G.Op('conv', x=x, w=w, wkey='w', bias=bias, bkey='b', residual=res, y=y, out_stats=ostats, bn=bn, epi='plain',
+              epi_x=None, epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
+    bt.realise().run([op], backend)
+    bt.compare(y, label='conv y %s' % (case,), **TOL[dtype])
+    if use_stats:
+        scale = N * P * Q
+        bt.compare(ostats, atol=TOL[dtype]['atol'] * scale, rtol=TOL[dtype]['rtol'], label='conv out_stats')
+
+
+DGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1), (2, 8, 8, 64, 128, 1, 0), (1, 6, 5, 16, 32, 3, 1), (2, 32, 32, 64, 64, 3, 1)]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', DGRAD_CASES)
+def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
+    """Data gradient of y = conv(relu(bn(x))) w.r.t. bn output: flipped weights via wprep, ReLU mask and BN sums."""
+    N, H, W, C, K, Rr, pad = case            # forward conv C -> K
+    gen = torch.Generator().manual_seed(7 + sum(case))
+    bt = Bench(dtype)
+    P, Q = H + 2 * pad - Rr + 1, W + 2 * pad - Rr + 1
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act((N, H, W, C), x_val, 'x')
+    dy = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K), 'dy')
+    wm = bt.buf('param', (K, Rr, Rr, C), rnd(gen, K, Rr, Rr, C, scale=1.0 / np.sqrt(C * Rr * Rr)))
+    wb = bt.buf('wlp', (C, Rr, Rr, K))
+    prev = bt.act((N, H, W, C), 0.5 * rnd(gen, N, H, W, C), 'prev')     # accumulate source (aliases dz)
+    bn = make_bn(bt, gen, C, 'train')
+    bn.count = N * H * W
+    xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
+    bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+    bst = bt.buf('stats', (2, C), torch.zeros(2, C, dtype=torch.float64))
+    ops = [G.Op('wprep', entries=[{'w': wm, 'w_fwd': None, 'w_bwd': wb}]),
+           G.Op('conv', x=dy, w=wb, wkey='w', bias=None, bkey=None, residual=prev, y=prev, out_stats=None, bn=None,
+                epi='bnrelu_bwd', epi_x=x, epi_bn=bn, epi_stats=bst, dims=(N, P, Q, K, C, Rr, Rr, 1, Rr - 1 - pad, H, W))]
+    bt.realise().run(ops, backend)
+    bt.compare(wb, atol=1e-6 if dtype == 0 else 1e-2, rtol=0, label='wprep w_bwd')
+    bt.compare(prev, label='dgrad dz %s' % (case,), **TOL[dtype])
+    bt.compare(bst, atol=TOL[dtype]['atol'] * N * H * W, rtol=TOL[dtype]['rtol'], label='dgrad bn sums')
+
+
+WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), (1, 9, 7, 16, 16, 3, 1, False),
+               (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True)]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv_wgrad(case, dtype, backend):
+    N, H, W, C, K, Rr, pad, use_bn = case
+    gen = torch.Generator().manual_seed(11 + sum(case[:7]))
+    bt = Bench(dtype)
+    P, Q = H + 2 * pad - Rr + 1, W + 2 * pad - Rr + 1
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act((N, H, W, C), x_val, 'x')
+    dy = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K, scale=0.1), 'dy')
+    dw = bt.buf('grad', (K, Rr, Rr, C), torch.zeros(K, Rr, Rr, C))
+    db = bt.buf('grad', (K,), torch.zeros(K))
+    bn = None
+    if use_bn:
+        bn = make_bn(bt, gen, C, 'train')
+        bn.count = N * H * W
+        xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
+        bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+    op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
+    bt.realise().run([op], backend)
+    m = N * P * Q
+    tol = dict(atol=2e-4 + 1e-6 * m, rtol=2e-4) if dtype == 0 else dict(atol=2e-2 + 2e-5 * m, rtol=3e-2)
+    bt.compare(dw, label='wgrad dw %s' % (case,), **tol)
+    bt.compare(db, label='wgrad dbias', **tol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 64, 64, 16), (1, 128, 96, 32), (2, 32, 48, 64)])
+def test_stem(case, dtype):
+    N, H, W, K = case
+    gen = torch.Generator().manual_seed(3 + sum(case))
+    bt = Bench(dtype)
+    P, Q = H // 2, W // 2
+    img = bt.buf('image', (N, 3, H, W), rnd(gen, N, 3, H, W))
+    w = bt.buf('param', (K, 7, 7, 3), rnd(gen, K, 7, 7, 3, scale=1 / np.sqrt(147)))
+    b = bt.buf('param', (K,), 0.1 * rnd(gen, K))
+    y = bt.act((N, P, Q, K), None, 'y')
+    st = bt.buf('stats', (2, K), torch.zeros(2, K, dtype=torch.float64))
+    dy = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K, scale=0.1), 'dy')
+    dw = bt.buf('grad', (K, 7, 7, 3), torch.zeros(K, 7, 7, 3))
+    db = bt.buf('grad', (K,), torch.zeros(K))
+    ops = [G.Op('stem_fwd', image=img, w=w, bias=b, y=y, out_stats=st, dims=(N, H, W, K, P, Q)),
+           G.Op('stem_wgrad', image=img, dy=dy, dw=dw, dbias=db, dims=(N, H, W, K, P, Q))]
+    bt.realise().run(ops, 0)
+    bt.compare(y, label='stem y', **TOL[dtype])
+    bt.compare(st, atol=TOL[dtype]['atol'] * N * P * Q, rtol=TOL[dtype]['rtol'], label='stem stats')
+    m = N * P * Q
+    tol = dict(atol=2e-4 + 1e-6 * m, rtol=2e-4) if dtype == 0 else dict(atol=2e-2 + 2e-5 * m, rtol=3e-2)
+    bt.compare(dw, label='stem dw', **tol)
+    bt.compare(db, label='stem dbias', **tol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (1, 6, 10, 16), (2, 8, 8, 256), (3, 4, 4, 48)])
+def test_elementwise_ops(shape, dtype):
+    N, H, W, C = shape
+    gen = torch.Generator().manual_seed(5 + sum(shape))
+    bt = Bench(dtype)
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act(shape, x_val, 'x')
+    half = (N, H // 2, W // 2, C)
+    lo = bt.act(half, rnd(gen, *half), 'lo')
+    dy = bt.act(shape, rnd(gen, *shape), 'dy')
+    dyh = bt.act(half, rnd(gen, *half), 'dyh')
+    acc = bt.act(shape, rnd(gen, *shape), 'acc')
+    acch = bt.act(half, rnd(gen, *half), 'acch')
+    bn = make_bn(bt, gen, C, 'train')
+    bn.count = N * H * W
+    xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
+    bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+
+    def z():
+        return bt.buf('stats', (2, C), torch.zeros(2, C, dtype=torch.float64))
+    y1, y2, y3, y4, y5, y6, y7, y8 = [bt.act(s, None, 'y%d' % i) for i, s in enumerate(
+        [shape, shape, shape, half, shape, shape, half, shape])]
+    s1, s4, s6, bst = z(), z(), z(), z()
+    dg = bt.buf('grad', (C,), torch.zeros(C))
+    dbt = bt.buf('grad', (C,), torch.zeros(C))
+
+    def ew(op, dims, **kw):
+        d = dict(x=None, x2=None, dy=None, add=None, out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None)
+        d.update(kw)
+        return G.Op('ew', op=op, dims=dims, **d)
+    ops = [
+        ew('bnrelu_fwd', shape, x=x, y=y1, bn=bn, out_stats=s1),
+        ew('bnrelu_bwd_r', shape, x=x, dy=dy, y=y2, bn=bn, bstats=bst),
+        ew('bn_bwd_apply', shape, x=x, dy=y2, add=acc, y=y3, bn=bn, bstats=bst, dgamma=dg, dbeta=dbt),
+        ew('maxpool_fwd', shape, x=x, y=y4, out_stats=s4),
+        ew('maxpool_bwd', shape, x=x, dy=dyh, add=acc, y=y5),
+        ew('upadd_fwd', shape, x=x, x2=lo, y=y6, out_stats=s6),
+        ew('sumpool', shape, x=dy, add=acch, y=y7),
+        ew('add', shape, x=x, x2=dy, y=y8),
+    ]
+    bt.realise().run(ops, 0)
+    for name, t in (('bnrelu_fwd', y1), ('bnrelu_bwd_r', y2), ('bn_bwd_apply', y3), ('maxpool_fwd', y4),
+                    ('maxpool_bwd', y5), ('upadd_fwd', y6), ('sumpool', y7), ('add', y8)):
+        bt.compare(t, label=name, **TOL[dtype])
+    n = N * H * W
+    for name, t in (('stats bnrelu', s1), ('stats maxpool', s4), ('stats upadd', s6), ('bstats', bst)):
+        bt.compare(t, atol=TOL[dtype]['atol'] * n, rtol=TOL[dtype]['rtol'], label=name)
+    bt.compare(dg, atol=TOL[dtype]['atol'] * n, rtol=TOL[dtype]['rtol'], label='dgamma')
+    bt.compare(dbt, atol=TOL[dtype]['atol'] * n, rtol=TOL[dtype]['rtol'], label='dbeta')
+
+
+def test_maxpool_bwd_ties_first_max():
+    """All-equal windows: torch routes the gradient to the first element in scan order; so must we."""
+    bt = Bench(0)
+    shape = (1, 4, 4, 16)
+    x = bt.act(shape, torch.ones(shape), 'x')
+    dy = bt.act((1, 2, 2, 16), torch.arange(64.).reshape(1, 2, 2, 16) + 1, 'dy')
+    y = bt.act(shape, None, 'y')
+    op = G.Op('ew', op='maxpool_bwd', dims=shape, x=x, x2=None, dy=dy, add=None, y=y, out_stats=None, bstats=None,
+              dgamma=None, dbeta=None, bn=None)
+    bt.realise().run([op], 0)
+    bt.compare(y, atol=0, rtol=0, label='maxpool ties')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 16, 16, 2, True), (3, 17, 12, 9, 1, True), (2, 16, 64, 64, 4, False)])
+def test_loss(case, dtype):
+    B, J, H, W, S, nchw = case
+    gen = torch.Generator().manual_seed(13 + sum(case[:5]))
+    dev = torch.device('cuda:0')
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    outs = [rnd(gen, B, H, W, J).to(tdt) for _ in range(S)]
+    teacher = rnd(gen, B, H, W, J).to(tdt)
+    target = torch.rand(B, J, H, W, generator=gen)
+    wgt = (torch.rand(B, J, generator=gen) * 1.5) * (torch.rand(B, J, generator=gen) < 0.8)
+    alpha = 0.3
+    # specification (include/fpd_amd.h fpd_loss_t), fp64
+    g = target.permute(0, 2, 3, 1).double()
+    w2 = (wgt.double() ** 2)[:, None, None, :]
+    cnt = B * J * H * W
+    pose = sum(0.5 * (w2 * (o.double() - g) ** 2).sum() / cnt for o in outs)
+    kd = sum(0.5 * (w2 * (o.double() - teacher.double()) ** 2).sum() / cnt for o in outs)
+    grads = [w2 * ((1 - alpha) * (o.double() - g) + alpha * (o.double() - teacher.double())) / cnt for o in outs]
+    a = R.LossT()
+    a.B, a.J, a.H, a.W, a.S, a.dtype, a.target_nchw, a.alpha = B, J, H, W, S, dtype, 1 if nchw else 0, alpha
+    d_outs = [o.to(dev) for o in outs]
+    d_douts = [torch.zeros_like(o) for o in d_outs]
+    for i in range(S):
+        a.out[i], a.dout[i] = d_outs[i].data_ptr(), d_douts[i].data_ptr()
+    d_t = teacher.to(dev)
+    d_tg = (target if nchw else target.permute(0, 2, 3, 1).contiguous()).to(dev)
+    d_w = wgt.float().to(dev)
+    losses = torch.zeros(2, dtype=torch.float64, device=dev)
+    a.teacher, a.target, a.weight, a.losses, a.grad_scale = d_t.data_ptr(), d_tg.data_ptr(), d_w.data_ptr(), losses.data_ptr(), 1.0
+    R.check(R.lib().fpd_loss(a, R.current_stream()))
+    torch.cuda.synchronize()
+    l = losses.cpu()
+    assert abs(l[0].item() - pose.item()) < 1e-6 * max(1, pose.item()), (l, pose)
+    assert abs(l[1].item() - kd.item()) < 1e-6 * max(1, kd.item()), (l, kd)
+    for i in range(S):
+        got = d_douts[i].cpu().double()
+        tol = 1e-9 if dtype == 0 else 1e-2 * grads[i].abs().max().item()
+        assert (got - grads[i]).abs().max().item() <= tol + 1e-6 * grads[i].abs().max().item()
+
+
+def test_adam_matches_torch():
+    gen = torch.Generator().manual_seed(1)
+    n = 100003
+    dev = torch.device('cuda:0')
+    p0 = rnd(gen, n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=2.5e-4)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    lr = torch.full((1,), 2.5e-4, device=dev)
+    for it in range(3):
+        g = rnd(gen, n, scale=0.01)
+        ref.grad = g.clone()
+        opt.step()
+        gd = g.to(dev)
+        a = R.AdamT()
+        a.n, a.param, a.grad, a.m, a.v = n, p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.lr, a.beta1, a.beta2, a.eps, a.bias_corr1, a.bias_corr2, a.grad_scale = 0.0, 0.9, 0.999, 1e-8, 1.0, 1.0, 1.0
+        a.lr_dev, a.step_dev = lr.data_ptr(), step.data_ptr()
+        R.check(R.lib().fpd_adam(a, R.current_stream()))
+    torch.cuda.synchronize()
+    assert int(step.item()) == 3
+    assert (p.cpu() - ref.detach()).abs().max().item() < 2e-7
+
+
+def test_bn_update_running_and_layout_and_cast():
+    gen = torch.Generator().manual_seed(2)
+    bt = Bench(0)
+    C = 48
+    x = rnd(gen, 2, 5, 5, C) + 1
+    bn = make_bn(bt, gen, C, 'train')
+    bn.count = 50
+    bn.stats = bt.buf('stats', (2, C), tensor_stats(x))
+    bt.realise().run([G.Op('bnupd', bns=[bn])], 0)
+    bt.compare(bn.rmean, atol=1e-6, rtol=1e-6, label='running_mean')
+    bt.compare(bn.rvar, atol=1e-6, rtol=1e-6, label='running_var')
+    assert int(bt.gpu.view(bn.nbt).item()) == 1
+    # layout + cast round trips
+    dev = torch.device('cuda:0')
+    l, st = R.lib(), R.current_stream()
+    src = rnd(gen, 2, 17, 6, 5).to(dev)
+    for dtype, tdt in ((0, torch.float32), (1, torch.bfloat16)):
+        nhwc = torch.empty((2, 6, 5, 17), dtype=tdt, device=dev)
+        R.check(l.fpd_nchw_to_nhwc(src.data_ptr(), nhwc.data_ptr(), 2, 17, 6, 5, dtype, st))
+        back = torch.empty_like(src)
+        R.check(l.fpd_nhwc_to_nchw(nhwc.data_ptr(), back.data_ptr(), 2, 17, 6, 5, dtype, st))
+        torch.cuda.synchronize()
+        assert torch.equal(nhwc.float(), src.permute(0, 2, 3, 1).to(tdt).float())
+        assert torch.equal(back, src.to(tdt).float())
+    b16 = torch.empty(src.numel(), dtype=torch.bfloat16, device=dev)
+    R.check(l.fpd_cast(src.data_ptr(), b16.data_ptr(), src.numel(), 0, 1, st))
+    torch.cuda.synchronize()
+    assert torch.equal(b16, src.reshape(-1).to(torch.bfloat16))
+
+
+def test_error_paths_fail_loudly():
+    a = R.ConvT()
+    rc = R.lib().fpd_conv_forward(a, R.current_stream())
+    assert rc != 0 and b'null' in R.lib().fpd_last_error()
