@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
     __shared__ __attribute__((aligned(16))) T sB[BNT * LD];
     __shared__ float s_scale[FPD_MAXC], s_shift[FPD_MAXC];
     __shared__ float s_epi[4][BNT];
-    __shared__ float s_red[4][BNT][2];
+    __shared__ double s_red[4][BNT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, S = a.S, P = a.P, Q = a.Q;
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
     const T* ex = reinterpret_cast<const T*>(a.epi_x);
     const bool want_stats = (a.out_stats != nullptr) || (a.epi == FPD_EPI_BNRELU_BWD);
     const int col_l = lane & 31, rhalf = lane >> 5;
-    float s1[TN], s2[TN];
+    double s1[TN], s2[TN];   // fp64 from the first add: var = E[x^2]-E[x]^2 must survive |mean| >> std
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        s1[tn] = 0.f; s2[tn] = 0.f;
+        s1[tn] = 0.0; s2[tn] = 0.0;
         const int t = tn * 32 + col_l;
         const int k = n0 + t;
         const bool kok = k < K;
@@ -221,11 +221,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
                     const float xv = DT<T>::ld(ex + off);
                     const float z = fmaf(xv, esc, esh);
                     v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
-                    const float vr = DT<T>::rnd(v);
+                    const double vr = (double)DT<T>::rnd(v);
                     s1[tn] += vr;
-                    s2[tn] += vr * ((xv - emu) * eis);
+                    s2[tn] += vr * (double)((xv - emu) * eis);
                 } else if (want_stats) {
-                    const float vr = DT<T>::rnd(v);
+                    const double vr = (double)DT<T>::rnd(v);
                     s1[tn] += vr;
                     s2[tn] += vr * vr;
                 }
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
     if (want_stats) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const float t1 = s1[tn] + __shfl_xor(s1[tn], 32, 64);
-            const float t2 = s2[tn] + __shfl_xor(s2[tn], 32, 64);
+            const double t1 = s1[tn] + __shfl_xor(s1[tn], 32, 64);
+            const double t2 = s2[tn] + __shfl_xor(s2[tn], 32, 64);
             if (lane < 32) { s_red[wave][tn * 32 + lane][0] = t1; s_red[wave][tn * 32 + lane][1] = t2; }
         }
         __syncthreads();
@@ -245,10 +245,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
             if (k < K) {
-                const float u1 = s_red[0][t][0] + s_red[1][t][0] + s_red[2][t][0] + s_red[3][t][0];
-                const float u2 = s_red[0][t][1] + s_red[1][t][1] + s_red[2][t][1] + s_red[3][t][1];
-                atomicAdd(st + k, (double)u1);
-                atomicAdd(st + K + k, (double)u2);
+                const double u1 = s_red[0][t][0] + s_red[1][t][0] + s_red[2][t][0] + s_red[3][t][0];
+                const double u2 = s_red[0][t][1] + s_red[1][t][1] + s_red[2][t][1] + s_red[3][t][1];
+                atomicAdd(st + k, u1);
+                atomicAdd(st + K + k, u2);
             }
         }
     }

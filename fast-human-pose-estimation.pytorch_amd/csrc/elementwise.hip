@@ -24,7 +24,8 @@ template <typename T, int OP>
 __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
     constexpr int VEC = DT<T>::VEC;
     __shared__ float s_t0[FPD_MAXC], s_t1[FPD_MAXC], s_t2[FPD_MAXC], s_t3[FPD_MAXC];
-    __shared__ float s_sum[2][FPD_MAXC];
+    __shared__ float s_is[FPD_MAXC];
+    __shared__ double s_sum[2][FPD_MAXC];   // fp64 statistics from the first add
     const int tid = threadIdx.x;
     const int C = a.C, H = a.H, W = a.W, N = a.N;
     const int VP = C / VEC;              // vectors per pixel
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
                 s_t1[c] = (float)(a.bstats[c] / cnt);         // mean(dz)
                 s_t2[c] = (float)(a.bstats[C + c] / cnt);     // mean(dz * xhat)
                 s_t3[c] = mu;
-                s_sum[0][c] = is;
+                s_is[c] = is;
                 if (blockIdx.x == 0) {   // gradients of the BN affine parameters fall out of the two sums
                     if (a.dgamma) a.dgamma[c] = (float)a.bstats[C + c];
                     if (a.dbeta) a.dbeta[c] = (float)a.bstats[c];
@@ -60,12 +61,12 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
         }
     }
     if (STATS || BSTATS)
-        for (int c = tid; c < C; c += 256) { s_sum[0][c] = 0.f; s_sum[1][c] = 0.f; }
+        for (int c = tid; c < C; c += 256) { s_sum[0][c] = 0.0; s_sum[1][c] = 0.0; }
     __syncthreads();
 
-    float acc1[VEC], acc2[VEC];
+    double acc1[VEC], acc2[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) { acc1[j] = 0.0; acc2[j] = 0.0; }
 
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* x2 = reinterpret_cast<const T*>(a.x2);
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
                 for (int j = 0; j < VEC; ++j) {
                     const float z = fmaf(v[j], s_t0[cv + j], s_t1[cv + j]);
                     o[j] = (!a.bn.relu || z > 0.f) ? g[j] : 0.f;
-                    const float r = DT<T>::rnd(o[j]);
+                    const double r = (double)DT<T>::rnd(o[j]);
                     acc1[j] += r;
-                    acc2[j] += r * ((v[j] - s_t2[cv + j]) * s_t3[cv + j]);
+                    acc2[j] += r * (double)((v[j] - s_t2[cv + j]) * s_t3[cv + j]);
                 }
                 stv<T>(y + (size_t)pix * C + cv, o);
             } else if (OP == FPD_EW_BN_BWD_APPLY) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int c = cv + j;
-                    const float xhat = (v[j] - s_t3[c]) * s_sum[0][c];
+                    const float xhat = (v[j] - s_t3[c]) * s_is[c];
                     o[j] = s_t0[c] * (g[j] - s_t1[c] - xhat * s_t2[c]) + (add ? ad[j] : 0.f);
                 }
                 stv<T>(y + (size_t)pix * C + cv, o);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
             }
             if (STATS && do_stats) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { const float r = DT<T>::rnd(o[j]); acc1[j] += r; acc2[j] += r * r; }
+                for (int j = 0; j < VEC; ++j) { const double r = (double)DT<T>::rnd(o[j]); acc1[j] += r; acc2[j] += r * r; }
             }
         }
     }
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
         __syncthreads();
         double* dst = STATS ? a.out_stats : a.bstats;
         for (int c = tid; c < C; c += 256) {
-            atomicAdd(dst + c, (double)s_sum[0][c]);
-            atomicAdd(dst + C + c, (double)s_sum[1][c]);
+            atomicAdd(dst + c, s_sum[0][c]);
+            atomicAdd(dst + C + c, s_sum[1][c]);
         }
     }
 }

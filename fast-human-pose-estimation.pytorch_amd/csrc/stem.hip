@@ -72,13 +72,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const fpd_stem_t a) {
         if (py < P && px < Q) DT<T>::st(y + ((size_t)(n * P + py) * Q + px) * K + k, buf[p * LDO + k]);
     }
     if (a.out_stats != nullptr && tid < K) {
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
         for (int p = 0; p < TP; ++p) {
             const int py = ty0 + p / TW, px = tx0 + p % TW;
-            if (py < P && px < Q) { const float v = buf[p * LDO + tid]; s1 += v; s2 += v * v; }
+            if (py < P && px < Q) { const double v = (double)buf[p * LDO + tid]; s1 += v; s2 += v * v; }
         }
-        atomicAdd(a.out_stats + tid, (double)s1);
-        atomicAdd(a.out_stats + K + tid, (double)s2);
+        atomicAdd(a.out_stats + tid, s1);
+        atomicAdd(a.out_stats + K + tid, s2);
     }
 }
 

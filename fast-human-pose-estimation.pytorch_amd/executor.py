@@ -230,7 +230,8 @@ class GraphInstance:
             b = len(p)
             p.add(*self.low.memset('grad'))
             for op in g.bwd:
-                p.add(*self.low.op(op))
+                if op.kind != 'seed':
+                    p.add(*self.low.op(op))
             self.rng['bwd'] = (b, len(p))
         self._finalized = True
         return self

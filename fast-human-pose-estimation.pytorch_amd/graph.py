@@ -388,6 +388,9 @@ class HourglassGraph:
             o.grad = Act(o.shape, 'd:' + o.name)
             o.grad.persistent = True
             self.out_grads.append(o.grad)
+        # liveness marker: the output gradients are written (by the loss kernel or by autograd's seeds) BEFORE the
+        # first backward op runs, so they must be placed here, not at their first use deep inside the backward list
+        self.bwd.append(Op('seed', extra_in=list(self.outputs), extra_out=list(self.out_grads)))
         for op in reversed(self.fwd):
             if op.kind == 'conv':
                 self._conv_backward(op)

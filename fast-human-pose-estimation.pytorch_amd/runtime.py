@@ -132,6 +132,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FpdError('HIP extension %s is missing: run `python __graft_entry__.py` (build()) first; '
                        'there is no CPU fallback for the FPD path' % LIB_PATH)
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE our library is
+    # dlopen'ed so that libfpd_amd.so binds to the SAME runtime instance torch uses (streams, device pointers);
+    # loaded the other way round our kernels would talk to /opt/rocm's runtime and see "no ROCm-capable device".
+    import torch  # noqa: F401
+    try:
+        torch.cuda.is_available()
+    except Exception:
+        pass
     l = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(l, name)          # AttributeError if the symbol is not exported

@@ -244,5 +244,7 @@ def run(A, ops):
         for op in ops:
             if op.kind == 'memset':
                 A.t[op.arena][op.off:op.off + op.n].zero_()
+            elif op.kind == 'seed':
+                pass
             else:
                 RUN[op.kind](A, op)

@@ -59,6 +59,38 @@ def truth64(name):
     return r
 
 
+_TRAJ = {}
+
+
+def traj64(name, steps=3):
+    """fp64 oracle loss trajectory [[pose, kd, loss]] over `steps` Adam steps.  Adam's first update is
+    lr*sign(g), so sign flips of noise-level gradients make fp32 trajectories diverge: measured here, the
+    reference's own fp32 trajectory is 1.3e-3..1.5e-3 away from this one at steps 2-3 of 'tiny'."""
+    if name in _TRAJ:
+        return _TRAJ[name]
+    import numpy as np
+    c = CONFIGS[name]
+    s_sd, t_sd = state_dicts(name)
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
+    t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
+    adam, traj = {}, []
+    for it in range(steps):
+        x, tg, tw = batch(name, it)
+        r = fpd_ref.fpd_step(s64, t64, c['s'][1], c['t'][1], x.double(), tg.double(), tw.double(), 0.5, adam_state=adam)
+        traj.append([r['pose'].item(), r['kd'].item(), r['loss'].item()])
+    _TRAJ[name] = np.array(traj)
+    return _TRAJ[name]
+
+
+def assert_traj(ours, gold32, name, slack=2.5, floor=1e-3):
+    import numpy as np
+    t64 = traj64(name, len(ours))
+    ref_dev = np.abs(np.asarray(gold32) - t64).max()
+    our_dev = np.abs(np.asarray(ours) - t64).max()
+    assert our_dev <= max(floor, slack * ref_dev), 'trajectory: |ours-fp64| %.3e vs reference fp32 deviation %.3e' % (our_dev, ref_dev)
+    return our_dev, ref_dev
+
+
 def assert_parity(ours, gold32, truth, label, floor=5e-5, slack=1.5, atol=1e-4):
     """ours / gold32 / truth: numpy arrays of one quantity.
       (1) |ours - truth64| <= max(floor, slack * |ref32 - truth64|)   -- no less accurate than the reference

@@ -104,3 +104,28 @@ def test_param_table_layout():
     for (o1, n1), (o2, _) in zip(offs, offs[1:]):
         assert o1 + n1 <= o2 and o2 % 4 == 0
     assert len(t.trainable_keys()) == sum(1 for k, _ in keys if 'running' not in k and 'tracked' not in k)
+
+
+def test_seeded_backward_without_loss_op():
+    """Autograd-compat path: d(out_s) are written before the backward list starts (no loss op in the plan).  The
+    planner must keep them live from the start of backward -- regression test for seeds being clobbered."""
+    c, table, g = build('tiny', train=True)
+    gold = _cases.load_golden('tiny')
+    s_sd, _ = _cases.state_dicts('tiny', gold)
+    x, tg, tw = _cases.batch('tiny')
+    act = G.plan_memory(g.fwd + g.bwd)
+    A = U.make_arenas(g, table, act)
+    U.load_params(A, table, s_sd)
+    A.t['image'].copy_(x.reshape(-1))
+    PI.run(A, [U.wprep_op(g, table)] + g.fwd)
+    teacher = torch.from_numpy(gold['toutput']).permute(0, 2, 3, 1)
+    cnt = float(tg.numel())
+    w2 = (tw.reshape(2, 16) ** 2)[:, None, None, :]
+    for o, d in zip(g.outputs, g.out_grads):
+        p = A.view(o.buf)
+        A.view(d.buf).copy_(w2 * (0.5 * (p - tg.permute(0, 2, 3, 1)) + 0.5 * (p - teacher)) / cnt)
+    PI.run(A, g.bwd)
+    flat = U.flat_grads_oihw(A, table)
+    tr = _cases.truth64('tiny')
+    t64 = torch.cat([tr['grads'][k].reshape(-1) for k in table.trainable_keys()]).numpy()
+    _cases.assert_parity(flat.numpy(), gold['grad_flat'], t64, 'seeded gradients', floor=2e-6, atol=1e-5)
