@@ -9,6 +9,7 @@
 #include "common.h"
 
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
@@ -55,7 +56,7 @@ const char* fpd_last_error(void) { return g_err; }
 int fpd_abi_version(void) { return 1; }
 int fpd_set_backend(int32_t backend) {
     const int prev = g_fpd_backend;
-    if (backend == FPD_BACKEND_MFMA || backend == FPD_BACKEND_NAIVE) g_fpd_backend = backend;
+    if (backend == FPD_BACKEND_MFMA || backend == FPD_BACKEND_NAIVE || backend == FPD_BACKEND_MFMA_GENERIC) g_fpd_backend = backend;
     return prev;
 }
 
@@ -79,7 +80,8 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
                 "conv: BNRELU_BWD epilogue needs epi_x, epi_stats and a train-mode epi_bn");
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_mfma_launch(*a, st);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
+    if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
     return rc ? rc : check_launch();
 }
@@ -91,7 +93,7 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "wgrad: bad dtype %d", a->dtype);
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_mfma_launch(*a, st);
+    if (g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
     return rc ? rc : check_launch();
 }

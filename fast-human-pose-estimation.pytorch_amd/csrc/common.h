@@ -12,6 +12,8 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 int fpd_fail(int code, const char* fmt, ...);  // sets fpd_last_error(), returns code
 #define FPD_CHECK_HIP(expr)                                                          \
@@ -27,12 +29,13 @@ int fpd_fail(int code, const char* fmt, ...);  // sets fpd_last_error(), returns
 extern int g_fpd_backend;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// two floats -> packed bf16x2 (lo = a), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t f2bf_pk(float a, float b) {
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&r);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf_pk(f, 0.f) & 0xffffu); }
 
 // ---- storage-type traits: 16-byte vectors of VEC elements --------------------------------
 template <typename T>
@@ -64,10 +67,7 @@ struct DT<bf16_t> {
         f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
     }
     static __device__ __forceinline__ uint4 pack(const float* f) {
-        return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16),
-                          (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                          (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16),
-                          (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+        return make_uint4(f2bf_pk(f[0], f[1]), f2bf_pk(f[2], f[3]), f2bf_pk(f[4], f[5]), f2bf_pk(f[6], f[7]));
     }
 };
 

@@ -1,0 +1,208 @@
+// Shared epilogue of the implicit-GEMM conv kernels: each wave holds TN accumulators of a 32x32 MFMA tile
+// (rows = 32 consecutive output pixels starting at m_wave, cols = output channels n0 + tn*32 ...).
+//   y = acc + bias (+ residual); then either
+//     - batch statistics of y for the next train-mode BN            (out_stats)
+//     - ReLU mask of epi_x + the two BatchNorm-backward sums        (FPD_EPI_BNRELU_BWD)
+// Statistics are accumulated in fp64 from the first add: var = E[x^2]-E[x]^2 must survive |mean| >> std.
+#pragma once
+#include "common.h"
+
+// s_epi: float[4][BNT] {scale, shift, mean, invstd} of epi_bn for this block's channels (BNRELU_BWD only)
+// s_red: double[4][BNT][2] scratch (may alias tile buffers: the caller guarantees they are no longer read)
+template <typename T, int TN>
+__device__ __forceinline__ void conv_epilogue(const fpd_conv_t& a, const f32x16* acc, const int m_wave, const int n0,
+                                              const int M, const float* s_epi, double* s_red) {
+    constexpr int BNT = 32 * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K;
+    T* __restrict__ y = reinterpret_cast<T*>(a.y);
+    const T* res = reinterpret_cast<const T*>(a.residual);
+    const T* ex = reinterpret_cast<const T*>(a.epi_x);
+    const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
+    const bool want_stats = (a.out_stats != nullptr) || bwd;
+    const int col_l = lane & 31, rhalf = lane >> 5;
+    double s1[TN], s2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        s1[tn] = 0.0; s2[tn] = 0.0;
+        const int t = tn * 32 + col_l;
+        const int k = n0 + t;
+        const bool kok = k < K;
+        const float bias = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+        if (bwd) { esc = s_epi[t]; esh = s_epi[BNT + t]; emu = s_epi[2 * BNT + t]; eis = s_epi[3 * BNT + t]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+            const int m = m_wave + row;
+            if (m < M && kok) {
+                const size_t off = (size_t)m * K + k;
+                float v = acc[tn][i] + bias;
+                if (res != nullptr) v += DT<T>::ld(res + off);
+                if (bwd) {
+                    const float xv = DT<T>::ld(ex + off);
+                    const float z = fmaf(xv, esc, esh);
+                    v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
+                    const double vr = (double)DT<T>::rnd(v);
+                    s1[tn] += vr;
+                    s2[tn] += vr * (double)((xv - emu) * eis);
+                } else if (want_stats) {
+                    const double vr = (double)DT<T>::rnd(v);
+                    s1[tn] += vr;
+                    s2[tn] += vr * vr;
+                }
+                DT<T>::st(y + off, v);
+            }
+        }
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const double t1 = s1[tn] + __shfl_xor(s1[tn], 32, 64);
+            const double t2 = s2[tn] + __shfl_xor(s2[tn], 32, 64);
+            if (lane < 32) { s_red[(wave * BNT + tn * 32 + lane) * 2 + 0] = t1; s_red[(wave * BNT + tn * 32 + lane) * 2 + 1] = t2; }
+        }
+        __syncthreads();
+        double* st = bwd ? a.epi_stats : a.out_stats;
+        for (int t = tid; t < BNT; t += 256) {
+            const int k = n0 + t;
+            if (k < K) {
+                double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { u1 += s_red[(w * BNT + t) * 2]; u2 += s_red[(w * BNT + t) * 2 + 1]; }
+                atomicAdd(st + k, u1);
+                atomicAdd(st + K + k, u2);
+            }
+        }
+    }
+}
+
+// fill s_epi for the BNRELU_BWD epilogue (call before a __syncthreads())
+template <int BNT>
+__device__ __forceinline__ void conv_epi_tables(const fpd_conv_t& a, const int n0, const int M, float* s_epi) {
+    if (a.epi != FPD_EPI_BNRELU_BWD) return;
+    for (int t = threadIdx.x; t < BNT; t += 256) {
+        const int k = n0 + t;
+        float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+        if (k < a.K) bn_coef(a.epi_bn, k, a.K, (double)M, sc, sh, mu, is);
+        s_epi[t] = sc; s_epi[BNT + t] = sh; s_epi[2 * BNT + t] = mu; s_epi[3 * BNT + t] = is;
+    }
+}
+
+// Vectorised epilogue (needs K % VEC == 0): the accumulators go through an fp32 LDS staging tile (64 rows at a
+// time) so that residual / epi_x are read and y is written as 16-byte vectors along the channel axis, each thread
+// owning one channel-vector column (its per-channel statistics stay in registers until the end).
+//   stage: >= 64*(32*TN+4) floats, 16-byte aligned; s_red: >= 4*32*TN*2 doubles (may alias stage)
+template <typename T, int TN>
+__device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32x16* acc, const int m0, const int n0,
+                                                  const int M, const float* s_epi, float* stage, double* s_red) {
+    constexpr int VEC = DT<T>::VEC;
+    constexpr int BNT = 32 * TN, LDST = BNT + 4, CVN = BNT / VEC, RSTEP = 256 / CVN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K;
+    const int cv = tid % CVN, row0 = tid / CVN;
+    const int k0 = n0 + cv * VEC;
+    const bool kok = k0 < K;
+    T* __restrict__ y = reinterpret_cast<T*>(a.y);
+    const T* res = reinterpret_cast<const T*>(a.residual);
+    const T* ex = reinterpret_cast<const T*>(a.epi_x);
+    const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
+    const bool want_stats = (a.out_stats != nullptr) || bwd;
+    float bias[VEC], esc[VEC], esh[VEC], emu[VEC], eis[VEC];
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        s1[e] = 0.0; s2[e] = 0.0;
+        bias[e] = (a.bias != nullptr && kok) ? a.bias[k0 + e] : 0.f;
+        esc[e] = esh[e] = emu[e] = eis[e] = 0.f;
+        if (bwd) {
+            const int t = cv * VEC + e;
+            esc[e] = s_epi[t]; esh[e] = s_epi[BNT + t]; emu[e] = s_epi[2 * BNT + t]; eis[e] = s_epi[3 * BNT + t];
+        }
+    }
+    const int col_l = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {
+        __syncthreads();                                   // staging tile free (and, first time, MFMA LDS reads done)
+        if ((wave >> 1) == phase) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (wave & 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+                    stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
+                }
+        }
+        __syncthreads();
+        for (int row = row0; row < 64; row += RSTEP) {
+            const int m = m0 + 64 * phase + row;
+            if (m < M && kok) {
+                float v[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * LDST + cv * VEC + q * 4);
+                    v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+                }
+                const size_t off = (size_t)m * K + k0;
+                if (res != nullptr) {
+                    float r[VEC];
+                    DT<T>::unpack(*reinterpret_cast<const uint4*>(res + off), r);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += r[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += bias[e];
+                if (bwd) {
+                    float xv[VEC];
+                    DT<T>::unpack(*reinterpret_cast<const uint4*>(ex + off), xv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float z = fmaf(xv[e], esc[e], esh[e]);
+                        v[e] = (!a.epi_bn.relu || z > 0.f) ? v[e] : 0.f;
+                        const double vr = (double)DT<T>::rnd(v[e]);
+                        s1[e] += vr;
+                        s2[e] += vr * (double)((xv[e] - emu[e]) * eis[e]);
+                    }
+                } else if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const double vr = (double)DT<T>::rnd(v[e]);
+                        s1[e] += vr;
+                        s2[e] += vr * vr;
+                    }
+                }
+                *reinterpret_cast<uint4*>(y + off) = DT<T>::pack(v);
+            }
+        }
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int o = CVN; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        __syncthreads();                                   // staging tile no longer read: s_red may alias it
+        if (lane < CVN) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s_red[(wave * BNT + cv * VEC + e) * 2 + 0] = s1[e];
+                s_red[(wave * BNT + cv * VEC + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        double* st = bwd ? a.epi_stats : a.out_stats;
+        for (int t = tid; t < BNT; t += 256) {
+            const int k = n0 + t;
+            if (k < K) {
+                double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { u1 += s_red[(w * BNT + t) * 2]; u2 += s_red[(w * BNT + t) * 2 + 1]; }
+                atomicAdd(st + k, u1);
+                atomicAdd(st + K + k, u2);
+            }
+        }
+    }
+}

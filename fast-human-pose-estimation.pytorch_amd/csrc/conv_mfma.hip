@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -92,14 +93,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
     const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
 
     bn_fill(a.bn, C, (double)a.N * H * W, s_scale, s_shift);
-    if (a.epi == FPD_EPI_BNRELU_BWD) {
-        for (int t = tid; t < BNT; t += 256) {
-            const int k = n0 + t;
-            float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
-            if (k < K) bn_coef(a.epi_bn, k, K, (double)M, sc, sh, mu, is);
-            s_epi[0][t] = sc; s_epi[1][t] = sh; s_epi[2][t] = mu; s_epi[3][t] = is;
-        }
-    }
+    conv_epi_tables<BNT>(a, n0, M, &s_epi[0][0]);
 
     // ---- per-thread staging coordinates (fixed over the K loop) ----
     const int cvA = (tid % VPR) * VEC;
@@ -194,64 +188,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const fpd_conv_t a) {
     }
 
     // ---- epilogue: bias, residual, (ReLU-mask + BN-backward sums | batch statistics), store ----
-    T* __restrict__ y = reinterpret_cast<T*>(a.y);
-    const T* res = reinterpret_cast<const T*>(a.residual);
-    const T* ex = reinterpret_cast<const T*>(a.epi_x);
-    const bool want_stats = (a.out_stats != nullptr) || (a.epi == FPD_EPI_BNRELU_BWD);
-    const int col_l = lane & 31, rhalf = lane >> 5;
-    double s1[TN], s2[TN];   // fp64 from the first add: var = E[x^2]-E[x]^2 must survive |mean| >> std
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        s1[tn] = 0.0; s2[tn] = 0.0;
-        const int t = tn * 32 + col_l;
-        const int k = n0 + t;
-        const bool kok = k < K;
-        const float bias = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
-        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
-        if (a.epi == FPD_EPI_BNRELU_BWD) { esc = s_epi[0][t]; esh = s_epi[1][t]; emu = s_epi[2][t]; eis = s_epi[3][t]; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
-            const int m = m0 + wave * 32 + row;
-            if (m < M && kok) {
-                const size_t off = (size_t)m * K + k;
-                float v = acc[tn][i] + bias;
-                if (res != nullptr) v += DT<T>::ld(res + off);
-                if (a.epi == FPD_EPI_BNRELU_BWD) {
-                    const float xv = DT<T>::ld(ex + off);
-                    const float z = fmaf(xv, esc, esh);
-                    v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
-                    const double vr = (double)DT<T>::rnd(v);
-                    s1[tn] += vr;
-                    s2[tn] += vr * (double)((xv - emu) * eis);
-                } else if (want_stats) {
-                    const double vr = (double)DT<T>::rnd(v);
-                    s1[tn] += vr;
-                    s2[tn] += vr * vr;
-                }
-                DT<T>::st(y + off, v);
-            }
-        }
-    }
-    if (want_stats) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const double t1 = s1[tn] + __shfl_xor(s1[tn], 32, 64);
-            const double t2 = s2[tn] + __shfl_xor(s2[tn], 32, 64);
-            if (lane < 32) { s_red[wave][tn * 32 + lane][0] = t1; s_red[wave][tn * 32 + lane][1] = t2; }
-        }
-        __syncthreads();
-        double* st = (a.epi == FPD_EPI_BNRELU_BWD) ? a.epi_stats : a.out_stats;
-        for (int t = tid; t < BNT; t += 256) {
-            const int k = n0 + t;
-            if (k < K) {
-                const double u1 = s_red[0][t][0] + s_red[1][t][0] + s_red[2][t][0] + s_red[3][t][0];
-                const double u2 = s_red[0][t][1] + s_red[1][t][1] + s_red[2][t][1] + s_red[3][t][1];
-                atomicAdd(st + k, u1);
-                atomicAdd(st + K + k, u2);
-            }
-        }
-    }
+    __syncthreads();   // all MFMA reads of sA/sB are done: s_red may reuse nothing here, it has its own storage
+    conv_epilogue<T, TN>(a, acc, m0 + wave * 32, n0, M, &s_epi[0][0], &s_red[0][0][0]);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -337,7 +275,7 @@ struct WgTile<bf16_t> {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t word = (uint32_t)f2bf(f0[j]) | ((uint32_t)f2bf(f1[j]) << 16);
+            const uint32_t word = f2bf_pk(f0[j], f1[j]);
             *reinterpret_cast<uint32_t*>(s + (cv + j) * LDT + 2 * pp) = word;
         }
     }

@@ -1,0 +1,283 @@
+// conv_tile: stride-1 1x1 / 3x3 "same" convolution as an implicit GEMM whose A operand is a halo tile staged ONCE
+// per channel chunk in LDS (BatchNorm+ReLU applied once per element on the way in) and then read by all R*S filter
+// taps at shifted LDS addresses; the weight tile of the next tap is prefetched into registers while the MFMAs of
+// the current tap run (two LDS weight buffers, one barrier per tap), and the next chunk's halo is in flight in
+// registers during all taps of the current chunk.
+//
+// Tile: 128 consecutive output pixels (whole image rows; needs 128 % W == 0) x 32*TN output channels, 4 wave64,
+// each wave 32 pixels x 32*TN channels.  LDS rows are 128 B of channels + 16 B pad (bf16: 64 ch, fp32: 32 ch).
+// Image-border rows are handled without branches in the MFMA loop: a lane whose tap row falls outside its image
+// reads its A fragment from a block of zero pixels; left/right borders are explicit zero columns in the halo.
+//
+// Same contract as conv_mfma_kernel (see conv_mfma.hip / include/fpd_amd.h); replaces the same reference calls.
+#include <algorithm>
+
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+template <typename T>
+struct TapMma;
+template <>
+struct TapMma<bf16_t> {
+    template <int TN, int BK, int LD>
+    static __device__ __forceinline__ void run(const bf16_t* arow, const bf16_t* sB, int lane, f32x16* acc) {
+        const int koff = 8 * (lane >> 5);
+        const bf16_t* brow = sB + (lane & 31) * LD + koff;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kk * 16 + koff);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + tn * 32 * LD + kk * 16);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tn], 0, 0, 0);
+            }
+        }
+    }
+};
+template <>
+struct TapMma<float> {
+    template <int TN, int BK, int LD>
+    static __device__ __forceinline__ void run(const float* arow, const float* sB, int lane, f32x16* acc) {
+        const int koff = (lane >> 5) * (BK / 2);
+        const float* brow = sB + (lane & 31) * LD + koff;
+#pragma unroll
+        for (int t4 = 0; t4 < BK / 8; ++t4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + koff + t4 * 4);
+            f32x4 b[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(brow + tn * 32 * LD + t4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[tn][j], acc[tn], 0, 0, 0);
+        }
+    }
+};
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+template <typename T, int TN, int BK>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const fpd_conv_t a, const int logW) {
+    constexpr int VEC = DT<T>::VEC;
+    constexpr int BNT = 32 * TN;
+    constexpr int LD = BK + 16 / (int)sizeof(T);
+    constexpr int VPR = BK / VEC, LOG_VPR = ilog2(VPR);
+    constexpr int NVB_TOT = BNT * VPR, NVB = (NVB_TOT + 255) / 256;
+    constexpr int NVH = 8;                       // halo vectors per thread (host guarantees the halo fits)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, pad = a.pad;
+    const int M = a.N * H * W, GR = a.N * H;     // pixels, flattened (n,h) rows
+    const int nrows = 128 >> logW, hrows = nrows + R - 1, WP = W + R - 1;
+    const int zero_px = hrows * WP;              // 3 all-zero pixels behind the halo
+    const int HP = zero_px + 3;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BNT;
+    const int g0 = m0 >> logW;
+
+    // LDS: [BN tables | epilogue tables] then the tile region (halo + 2 weight buffers), which the epilogue reuses
+    float* s_scale = reinterpret_cast<float*>(smem);
+    float* s_shift = s_scale + C;
+    float* s_epi = s_shift + C;
+    T* sH = reinterpret_cast<T*>(s_epi + 4 * BNT);
+    T* sB = sH + HP * LD;
+    float* stage = reinterpret_cast<float*>(sH);         // epilogue staging tile (after the last MFMA)
+    double* s_red = reinterpret_cast<double*>(sH);
+    const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+
+    // ---- one-time LDS initialisation: zero border columns + zero pixels; BN tables ----
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const int nb = (R == 3) ? 2 * hrows : 0;
+        for (int v = tid; v < (nb + 3) * VPR; v += 256) {
+            const int pz = v >> LOG_VPR, cv = (v & (VPR - 1)) * VEC;
+            const int px = pz < nb ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - nb);
+            *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
+        }
+    }
+    bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    conv_epi_tables<BNT>(a, n0, M, s_epi);
+
+    // ---- per-lane A addressing: output pixel -> halo row/col; invalid tap rows point at the zero pixels ----
+    const int ml = wave * 32 + (lane & 31);
+    const int ti = ml >> logW, tj = ml & (W - 1);
+    int ab0, ab1, ab2;
+    {
+        const int g = g0 + ti;
+        const int p = g % H;
+        const bool live = g < GR;
+        if (R == 3) {
+            ab0 = (live && p - 1 >= 0) ? ((ti + 0) * WP + tj) * LD : zero_px * LD;
+            ab1 = live ? ((ti + 1) * WP + tj) * LD : zero_px * LD;
+            ab2 = (live && p + 1 < H) ? ((ti + 2) * WP + tj) * LD : zero_px * LD;
+        } else {
+            ab0 = ab1 = ab2 = live ? (ti * WP + tj) * LD : zero_px * LD;
+        }
+    }
+
+    // ---- staging registers ----
+    const int nvtot = (hrows << logW) * VPR;
+    uint4 rh[NVH];
+    unsigned hmask = 0;
+    auto halo_load = [&](int c0) {
+        hmask = 0;
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            const int v = tid + i * 256;
+            rh[i] = make_uint4(0, 0, 0, 0);
+            if (v < nvtot) {
+                const int hr = v >> (logW + LOG_VPR);
+                const int rem = v & ((W << LOG_VPR) - 1);
+                const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
+                const int g = g0 - pad + hr;
+                if ((unsigned)g < (unsigned)GR) {
+                    rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(g * W + j) * C + c0 + cv));
+                    hmask |= 1u << i;
+                }
+            }
+        }
+    };
+    auto halo_store = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            const int v = tid + i * 256;
+            if (v < nvtot) {
+                const int hr = v >> (logW + LOG_VPR);
+                const int rem = v & ((W << LOG_VPR) - 1);
+                const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
+                uint4 val = rh[i];
+                if (a.bn.mode != FPD_BN_NONE) {
+                    float f[VEC];
+                    DT<T>::unpack(val, f);
+                    const bool ok = (hmask >> i) & 1u;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float t = bn_act(f[e], s_scale[c0 + cv + e], s_shift[c0 + cv + e], a.bn.relu);
+                        f[e] = ok ? t : 0.f;
+                    }
+                    val = DT<T>::pack(f);
+                }
+                *reinterpret_cast<uint4*>(sH + (hr * WP + j + pad) * LD + cv) = val;
+            }
+        }
+    };
+    int b_row[NVB], b_col[NVB];
+    bool b_ok[NVB];
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        const int v = tid + i * 256;
+        b_row[i] = v >> LOG_VPR;
+        b_col[i] = (v & (VPR - 1)) * VEC;
+        b_ok[i] = (v < NVB_TOT) && (n0 + b_row[i] < K);
+    }
+    uint4 rb[NVB];
+    const int RS = R * R;
+    auto b_load = [&](int tap, int c0) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (b_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(w + ((size_t)(n0 + b_row[i]) * RS + tap) * C + c0 + b_col[i]);
+        }
+    };
+    auto b_store = [&](int buf) {
+        T* dst = sB + buf * BNT * LD;
+#pragma unroll
+        for (int i = 0; i < NVB; ++i)
+            if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(dst + b_row[i] * LD + b_col[i]) = rb[i];
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+
+    const int nchunk = C / BK;
+    halo_load(0);
+    b_load(0, 0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = ch * BK;
+        const bool more = ch + 1 < nchunk;
+        __syncthreads();                 // previous chunk fully consumed (and, first time, tables/zero fill visible)
+        halo_store(c0);
+        b_store(0);
+        __syncthreads();
+        if (more) halo_load(c0 + BK);    // in flight during all taps of this chunk
+        if (RS > 1) b_load(1, c0); else if (more) b_load(0, c0 + BK);
+        int r = 0, s = 0;
+        for (int tap = 0; tap < RS; ++tap) {
+            const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
+            TapMma<T>::template run<TN, BK, LD>(sH + ab + s * LD, sB + (tap & 1) * BNT * LD, lane, acc);
+            if (tap + 1 < RS) {
+                b_store((tap + 1) & 1);
+                if (tap + 2 < RS) b_load(tap + 2, c0); else if (more) b_load(0, c0 + BK);
+                __syncthreads();
+            }
+            if (++s == R) { s = 0; ++r; }
+        }
+    }
+    if (K % VEC == 0) {
+        conv_epilogue_vec<T, TN>(a, acc, m0, n0, M, s_epi, stage, s_red);   // starts with a barrier
+    } else {
+        __syncthreads();                 // every wave is done reading the tile region before s_red (aliased) is written
+        conv_epilogue<T, TN>(a, acc, m0 + wave * 32, n0, M, s_epi, s_red);
+    }
+}
+
+template <typename T, int TN, int BK>
+int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
+    constexpr int LD = BK + 16 / (int)sizeof(T);
+    const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
+    const size_t tile = (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)2 * 32 * TN * LD * sizeof(T);
+    const size_t epi = std::max((size_t)64 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
+    const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile, epi);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        configured = lds;
+    }
+    const int M = a.N * a.H * a.W;
+    dim3 grid(cdiv(M, 128), cdiv(a.K, 32 * TN));
+    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, logW);
+    return 0;
+}
+
+template <typename T, int BK>
+int launch_tile_tn(const fpd_conv_t& a, int logW, hipStream_t st) {
+    const int mt = cdiv(a.N * a.H * a.W, 128);
+    int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
+    while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;     // small layers: more, shorter blocks
+    if (tn == 4) return launch_tile<T, 4, BK>(a, logW, st);
+    if (tn == 2) return launch_tile<T, 2, BK>(a, logW, st);
+    return launch_tile<T, 1, BK>(a, logW, st);
+}
+
+}  // namespace
+
+// returns 1 when the shape is outside this kernel's domain (caller tries the generic MFMA kernel next)
+int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st) {
+    if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return 1;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2 || (a.W & (a.W - 1)) != 0) return 1;
+    if (a.C % 16 != 0 || a.C > 256) return 1;
+    if (a.epi == FPD_EPI_BNRELU_BWD && a.K > FPD_MAXC) return 1;
+    int logW = 0;
+    while ((1 << logW) < a.W) ++logW;
+    const int hrows = (128 >> logW) + a.R - 1;
+    if (a.dtype == FPD_BF16) {
+        const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
+        if (hrows * a.W * (bk / 8) > 2048) return 1;
+        if (bk == 64) return launch_tile_tn<bf16_t, 64>(a, logW, st);
+        if (bk == 32) return launch_tile_tn<bf16_t, 32>(a, logW, st);
+        return launch_tile_tn<bf16_t, 16>(a, logW, st);
+    }
+    const int bk = (a.C % 32 == 0) ? 32 : 16;
+    if (hrows * a.W * (bk / 4) > 2048) return 1;
+    if (bk == 32) return launch_tile_tn<float, 32>(a, logW, st);
+    return launch_tile_tn<float, 16>(a, logW, st);
+}

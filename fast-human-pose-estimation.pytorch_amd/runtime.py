@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libfpd_amd.so')
 F32, BF16 = 0, 1
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
 EPI_PLAIN, EPI_BNRELU_BWD = 0, 1
-BACKEND_MFMA, BACKEND_NAIVE = 0, 1
+BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD) = range(10)

@@ -30,7 +30,9 @@ typedef void* fpd_stream_t; /* hipStream_t */
 enum { FPD_F32 = 0, FPD_BF16 = 1 };
 enum { FPD_BN_NONE = 0, FPD_BN_TRAIN = 1, FPD_BN_EVAL = 2 };
 enum { FPD_EPI_PLAIN = 0, FPD_EPI_BNRELU_BWD = 1 };
-enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1 };
+enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1, FPD_BACKEND_MFMA_GENERIC = 2 };
+/* MFMA: halo-tile kernel where it applies, else the generic MFMA kernel, else the direct kernel;
+ * MFMA_GENERIC skips the halo-tile kernel; NAIVE forces the direct kernels (cross-check). */
 
 /* nn.BatchNorm2d(momentum=0.1) (hourglass.py:18-25,118,162) applied on the fly while a consumer
  * loads the tensor: a = relu?(x*scale+shift).  TRAIN: scale/shift derive from the batch

@@ -106,7 +106,7 @@ def tensor_stats(x):   # x [N,H,W,C] -> [2,C] fp64
 
 
 TOL = {0: dict(atol=2e-4, rtol=2e-4), 1: dict(atol=3e-2, rtol=3e-2)}
-BACKENDS = [0, 1]
+BACKENDS = [0, 1, 2]      # halo-tile MFMA (default dispatch) / direct kernels / generic MFMA kernel
 DTYPES = [0, 1]
 
 CONV_CASES = [
