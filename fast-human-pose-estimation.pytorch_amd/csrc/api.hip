@@ -11,6 +11,7 @@
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
+int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
@@ -93,7 +94,8 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "wgrad: bad dtype %d", a->dtype);
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
-    if (g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_tile_launch(*a, st);
+    if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
     return rc ? rc : check_launch();
 }
