@@ -270,7 +270,7 @@ class FusedFPDStep:
     No host synchronisation inside; losses are read back only when asked for."""
 
     def __init__(self, student_state, student_cfg, teacher_state, teacher_cfg, batch, height, width, alpha,
-                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1):
+                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1, adam=None):
         dev = student_state.device
         self.dtype = student_state.dtype
         self.alpha, self.world_size = alpha, world_size
@@ -296,10 +296,14 @@ class FusedFPDStep:
         # optimizer state (torch.optim.Adam semantics, lib/utils/utils.py:69-73)
         n = student_state.table.sizes['param']
         self.n_param = n
-        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        if adam is not None:        # share moments / step / lr with a lib.utils.utils.FusedAdam (checkpointable state)
+            self.m, self.v, self.lr_dev, self.step_dev = adam.m, adam.v, adam.lr_dev, adam.step_dev
+            betas, eps = adam.param_groups[0]['betas'], adam.param_groups[0]['eps']
+        else:
+            self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.betas, self.eps = betas, eps
         a = R.AdamT()
         a.n = n

@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""FPD training entry point with the reference's command line (/root/reference/tools/fpd_train.py:44-83):
+
+    python tools/fpd_train.py --cfg S.yaml --tcfg T.yaml [KEY VALUE ...]
+    python -m torch.distributed.run --nproc-per-node 8 tools/fpd_train.py --cfg ... --tcfg ...      (data parallel)
+
+Same flow as the reference's main() (:96-294): config merge, student `models.<NAME>.get_pose_net(cfg, is_train=True)`,
+teacher from the cloned config merged with --tcfg, strict teacher-checkpoint load, two JointsMSELoss criteria,
+Adam + MultiStepLR, epoch loop -> core.function.fpd_train -> checkpoint.  What differs: one process per GPU with an
+RCCL gradient all-reduce instead of nn.DataParallel; the models run on the HIP path; DATASET.DATASET 'synthetic'
+(the default -- MPII/COCO are not available offline) feeds seeded synthetic crops, and KD.TEACHER 'synthetic' builds a
+random teacher with calibrated BN statistics instead of loading a checkpoint.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.utils.data  # noqa: E402
+
+from fpd_amd import dist as fdist, executor as E, synth  # noqa: E402
+from fpd_amd.lib import models  # noqa: E402,F401
+from fpd_amd.lib.config import cfg, update_config  # noqa: E402
+from fpd_amd.lib.core.function import fpd_train  # noqa: E402
+from fpd_amd.lib.core.loss import JointsMSELoss  # noqa: E402
+from fpd_amd.lib.utils.utils import get_optimizer, load_checkpoint, save_checkpoint  # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='Train keypoints network (FPD)')
+    p.add_argument('--cfg', help='student experiment configure file name', required=True, type=str)
+    p.add_argument('--tcfg', help='teacher experiment configure file name', default='', type=str)
+    p.add_argument('opts', help='Modify config options using the command-line', default=None, nargs=argparse.REMAINDER)
+    p.add_argument('--modelDir', default='', type=str)
+    p.add_argument('--logDir', default='', type=str)
+    p.add_argument('--dataDir', default='', type=str)
+    p.add_argument('--max-iters', type=int, default=0, help='stop every epoch after this many iterations (smoke runs)')
+    return p.parse_args()
+
+
+class SyntheticPose(torch.utils.data.Dataset):
+    """Seeded synthetic samples shaped like JointsDataset.__getitem__ (lib/dataset/JointsDataset.py:113-198)."""
+
+    def __init__(self, cfg, n, seed):
+        self.n, self.seed = n, seed
+        self.joints = cfg.MODEL.NUM_JOINTS
+        self.image, self.heat, self.sigma = tuple(cfg.MODEL.IMAGE_SIZE), tuple(cfg.MODEL.HEATMAP_SIZE), cfg.MODEL.SIGMA
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        x, t, w = synth.make_batch(self.seed * 1000003 + i, 1, self.joints, self.image, self.heat, self.sigma)
+        return x[0], t[0], w[0], {'index': i}
+
+
+def get_train_type(train_type, checkpoint):
+    """tools/fpd_train.py:85-94."""
+    if train_type == 'NORMAL':
+        return train_type
+    if train_type == 'FPD' and (checkpoint == 'synthetic' or (checkpoint and os.path.exists(checkpoint))):
+        return 'FPD'
+    if train_type == 'FPD':
+        sys.exit('ERROR: teacher checkpoint is not existed.')
+    sys.exit('ERROR: please change train type {} to NORMAL or FPD.'.format(train_type))
+
+
+def main():
+    args = parse_args()
+    update_config(cfg, args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format='%(asctime)-15s %(message)s')
+    logger = logging.getLogger()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    train_type = get_train_type(cfg.KD.TRAIN_TYPE, cfg.KD.TEACHER)
+    if train_type != 'FPD':
+        sys.exit('this entry point implements the FPD path; set KD.TRAIN_TYPE FPD (plain training is out of scope)')
+    out_dir = os.path.join(cfg.OUTPUT_DIR, cfg.DATASET.DATASET, cfg.MODEL.NAME,
+                           os.path.basename(args.cfg).split('.')[0])
+    os.makedirs(out_dir, exist_ok=True)
+
+    torch.manual_seed(1)
+    model = eval('models.' + cfg.MODEL.NAME + '.get_pose_net')(cfg, is_train=True)          # :122-124
+    tcfg = cfg.clone()                                                                        # :128-131
+    if args.tcfg:
+        tcfg.merge_from_file(args.tcfg)
+    torch.manual_seed(2)
+    tmodel = eval('models.' + tcfg.MODEL.NAME + '.get_pose_net')(tcfg, is_train=False)       # :135-137
+    if cfg.KD.TEACHER != 'synthetic':
+        load_checkpoint(cfg.KD.TEACHER, tmodel, strict=True, model_info='teacher_' + tcfg.MODEL.NAME)   # :139-141
+    if cfg.TRAIN.CHECKPOINT:
+        load_checkpoint(cfg.TRAIN.CHECKPOINT, model, strict=True, model_info='student_' + cfg.MODEL.NAME)
+    model, tmodel = fdist.DataParallelReplica(model.to(dev)), fdist.DataParallelReplica(tmodel.to(dev))
+    if world > 1:
+        fdist.broadcast_state(dist, model.module)
+        fdist.broadcast_state(dist, tmodel.module)
+
+    pose_criterion = JointsMSELoss(use_target_weight=cfg.LOSS.USE_TARGET_WEIGHT).to(dev)     # :145-147,177-179
+    kd_pose_criterion = JointsMSELoss(use_target_weight=tcfg.LOSS.USE_TARGET_WEIGHT).to(dev)
+
+    if cfg.DATASET.DATASET != 'synthetic':
+        sys.exit('dataset %r is not available here (CPU-side MPII/COCO pipeline is out of scope); use DATASET.DATASET synthetic'
+                 % cfg.DATASET.DATASET)
+    bs = cfg.TRAIN.BATCH_SIZE_PER_GPU
+    train_set = SyntheticPose(cfg, cfg.DATASET.NUM_SAMPLES, seed=rank)
+    loader = torch.utils.data.DataLoader(train_set, batch_size=bs, shuffle=cfg.TRAIN.SHUFFLE, num_workers=0,
+                                         pin_memory=cfg.PIN_MEMORY, drop_last=True)
+    if args.max_iters:
+        import itertools
+        full = loader
+
+        class _Limited(object):
+            def __iter__(self):
+                return itertools.islice(iter(full), args.max_iters)
+
+            def __len__(self):
+                return min(len(full), args.max_iters)
+        loader = _Limited()
+    if cfg.KD.TEACHER == 'synthetic':          # give the random teacher sane eval-mode BN statistics once
+        x0 = next(iter(loader))[0]
+        t = tmodel.module
+        cal = E.GraphInstance(t.device_state(), t.cfg_hg, x0.shape[0], x0.shape[2], x0.shape[3], train=True).finalize()
+        cal.image().copy_(x0)
+        cal.run('prep'); cal.run('fwd')
+        cal.calibrate_running_stats()
+        del cal
+
+    optimizer = get_optimizer(cfg, model)                                                     # :218
+    begin_epoch, best_perf = cfg.TRAIN.BEGIN_EPOCH, 0.0
+    ckpt = os.path.join(out_dir, 'checkpoint.pth')
+    if cfg.AUTO_RESUME and os.path.exists(ckpt):                                              # :224-234
+        state = torch.load(ckpt, map_location=dev)
+        begin_epoch, best_perf = state['epoch'], state['perf']
+        model.load_state_dict(state['state_dict'])
+        optimizer.load_state_dict(state['optimizer'])
+        logger.info("=> loaded checkpoint '%s' (epoch %d)", ckpt, state['epoch'])
+    sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR,
+                                                 last_epoch=begin_epoch - 1)                  # :236-239
+    allreduce = fdist.make_allreduce(dist) if world > 1 else None
+    writer_dict = {'writer': None, 'train_global_steps': 0, 'valid_global_steps': 0}
+    for epoch in range(begin_epoch, cfg.TRAIN.END_EPOCH):                                     # :252-286
+        t0 = time.time()
+        loss = fpd_train(cfg, loader, model, tmodel, pose_criterion, kd_pose_criterion, optimizer, epoch, out_dir,
+                         cfg.LOG_DIR, writer_dict, allreduce=allreduce, world_size=world)
+        sched.step()
+        torch.cuda.synchronize()
+        logger.info('=> epoch %d done in %.1fs, %.1f samples/s, last logged loss %.5f', epoch, time.time() - t0,
+                    len(loader) * bs * world / max(time.time() - t0, 1e-9), loss)
+        if rank == 0:
+            save_checkpoint({'epoch': epoch + 1, 'model': cfg.MODEL.NAME, 'state_dict': model.state_dict(),
+                             'best_state_dict': model.module.state_dict(), 'perf': -loss,
+                             'optimizer': optimizer.state_dict()}, True, out_dir)
+    if rank == 0:
+        torch.save(model.module.state_dict(), os.path.join(out_dir, 'final_state.pth'))      # :288-294
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
