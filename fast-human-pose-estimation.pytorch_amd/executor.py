@@ -277,13 +277,18 @@ class FusedFPDStep:
         self.B, self.J = batch, student_cfg['J']
         # teacher first: it owns the image buffer; its last-stack map is read in place by the loss kernel
         self.teacher = None
-        image = None
+        self.tmap = [None, None]
         if teacher_state is not None:
             assert teacher_state.dtype == self.dtype
             self.teacher = GraphInstance(teacher_state, teacher_cfg, batch, height, width, train=False).finalize()
             self.teacher.run('prep')           # frozen weights: working copies are prepared once
-            image = self.teacher.A.tensor('image')
-        self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True, image=image)
+            nt = self.teacher.g.outputs[-1].numel
+            # the teacher runs one batch ahead on its own stream: its last-stack map is staged in two slots
+            self.tmap = [torch.zeros(nt, dtype=act_torch_dtype(self.dtype), device=dev) for _ in range(2)]
+            self.t_stream = torch.cuda.Stream(device=dev)
+            self.ev_t = [torch.cuda.Event(), torch.cuda.Event()]
+        self._k_t = self._k_s = 0
+        self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True)
         g = self.student.g
         self.hh, self.hw = g.outputs[0].shape[1:3]
         A = self.student.A
@@ -291,8 +296,11 @@ class FusedFPDStep:
         A.alloc('weight', self.B * self.J)
         A.alloc('losses', 4)
         self.student.mid_ops = [G.Op('loss', extra_in=list(g.outputs), extra_out=list(g.out_grads))]
-        self.student.mid_native = [self._add_loss]
+        self.student.mid_native = [lambda plan: self._add_loss(plan, 0)]
         self.student.finalize()
+        b = len(self.student.plan)                 # second loss op reading the other staged teacher map
+        self._add_loss(self.student.plan, 1)
+        self.student.rng['mid1'] = (b, len(self.student.plan))
         # optimizer state (torch.optim.Adam semantics, lib/utils/utils.py:69-73)
         n = student_state.table.sizes['param']
         self.n_param = n
@@ -321,7 +329,7 @@ class FusedFPDStep:
         self.student.rng['adam'] = (b, len(self.student.plan))
         self._dist_work = None
 
-    def _add_loss(self, plan):
+    def _add_loss(self, plan, slot):
         A, g = self.student.A, self.student.g
         plan.add(*self.student.low.memset('losses'))
         s = R.LossT()
@@ -331,7 +339,7 @@ class FusedFPDStep:
             s.out[i] = A.ptr(o.buf)
             s.dout[i] = A.ptr(d.buf)
         if self.teacher is not None:
-            s.teacher = self.teacher.A.ptr(self.teacher.g.outputs[-1].buf)
+            s.teacher = self.tmap[slot].data_ptr()
         else:                                   # plain (non-KD) training: alpha must be 0, kd term reads the student map
             s.teacher = A.ptr(g.outputs[-1].buf)
         s.target, s.weight = A.tensor('target').data_ptr(), A.tensor('weight').data_ptr()
@@ -341,32 +349,68 @@ class FusedFPDStep:
 
     # ---- data ----
     def set_batch(self, inp, target, target_weight):
-        """Copy one loader batch (any device) into the step's fixed HBM buffers (async on the current stream)."""
+        """Copy one loader batch (any device) into the student's fixed HBM buffers (async on the current stream)."""
         self.student.image().copy_(inp, non_blocking=True)
         self.student.A.tensor('target').view(target.shape).copy_(target, non_blocking=True)
         self.student.A.tensor('weight').view(target_weight.shape).copy_(target_weight, non_blocking=True)
+        self._last_inp = inp
 
-    # ---- one iteration ----
-    def teacher_forward(self):
-        self.teacher.run('fwd')
+    # ---- one iteration = teacher_async(batch) + student_step(batch) ----
+    def teacher_async(self, inp=None):
+        """Frozen-teacher forward of one batch on the teacher stream.  It may be submitted one batch ahead of the
+        student step that consumes it: it then overlaps the previous batch's student forward/backward/Adam (it does
+        not depend on the student weights).  `inp` None = reuse the image already in the teacher's buffer."""
+        t = self.teacher
+        if t is None:
+            return
+        slot = self._k_t % 2
+        T = self.t_stream
+        T.wait_stream(torch.cuda.current_stream())      # inputs staged on the caller's stream; slot free (its loss ran)
+        with torch.cuda.stream(T):
+            if inp is not None:
+                t.image().copy_(inp, non_blocking=True)
+            t.run('fwd')
+            o = t.g.outputs[-1].buf
+            self.tmap[slot].copy_(t.A.tensor('act')[o.off:o.off + o.numel])
+            self.ev_t[slot].record(T)
+        self._k_t += 1
 
-    def step(self, allreduce=None):
-        """One FPD iteration on the current stream.  `allreduce(flat_grad)` is the DP hook."""
+    def student_step(self, allreduce=None):
+        """Student prep/forward, fused loss (against the staged teacher map), backward, [all-reduce], Adam."""
         s = self.student
+        slot = self._k_s % 2
         if self.teacher is not None:
-            self.teacher_forward()
-        if self._dist_work is not None:        # previous step's gradient exchange overlapped the teacher forward
+            assert self._k_t > self._k_s, 'teacher_async() must be submitted before student_step()'
+            torch.cuda.current_stream().wait_event(self.ev_t[slot])
+        if self._dist_work is not None:        # previous step's gradient exchange overlapped this step's teacher forward
             self._dist_work()
             self._dist_work = None
             s.run('adam')
         s.run('prep')
         s.run('fwd')
-        s.run('mid')
+        s.run('mid' if slot == 0 else 'mid1')
         s.run('bwd')
         if allreduce is not None:
             self._dist_work = allreduce(self.student.state.A.tensor('grad'))
         else:
             s.run('adam')
+        self._k_s += 1
+
+    def step(self, allreduce=None):
+        """Un-pipelined iteration on the batch given to set_batch(): teacher forward, then the student step."""
+        self.teacher_async(getattr(self, '_last_inp', None))
+        self.student_step(allreduce)
+
+    def run_pipelined(self, n_steps, allreduce=None):
+        """n_steps iterations on the staged batch with the teacher one batch ahead (exactly n_steps teacher forwards and
+        n_steps student steps are enqueued; the pipeline starts and ends empty)."""
+        inp = getattr(self, '_last_inp', None)
+        self.teacher_async(inp)
+        for i in range(n_steps):
+            if i + 1 < n_steps:
+                self.teacher_async(None)
+            self.student_step(allreduce)
+        self.flush()
 
     def flush(self):
         """Apply a pending (overlapped) optimizer update -- call after the last step()."""

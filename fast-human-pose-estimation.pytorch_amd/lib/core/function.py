@@ -1,7 +1,8 @@
 """`core.function.fpd_train` with the reference's signature (/root/reference/lib/core/function.py:99-187), driving
 the fused MI355X step (executor.FusedFPDStep): per batch the frozen-teacher forward, the student forward/backward, the
 pose + distillation JointsMSELoss of every stack, the data-parallel gradient exchange and Adam run as recorded HIP
-plans with no host synchronisation; losses / accuracy are read back only when a log line is due (PRINT_FREQ)."""
+plans with no host synchronisation; the teacher runs one batch ahead on its own stream (it does not depend on the
+student weights); losses / accuracy are read back only when a log line is due (PRINT_FREQ)."""
 import logging
 import time
 
@@ -57,18 +58,30 @@ def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_crite
     tmodel.eval()
     step = None
     end = time.time()
-    for i, (inp, target, target_weight, meta) in enumerate(train_loader):
+    it = iter(train_loader)
+    nxt = next(it, None)
+    i = -1
+    while nxt is not None:
+        i += 1
+        inp, target, target_weight, meta = nxt
         data_time.update(time.time() - end)
         if step is None or tuple(inp.shape) != tuple(step.student.image().shape):
+            if step is not None:
+                step.flush()
             step = fused_step_for(model, tmodel, optimizer, inp.shape, alpha, world_size)
+            step.teacher_async(inp)                    # pipeline prologue: teacher forward of the first batch
         if isinstance(optimizer, FusedAdam):
             optimizer.sync_lr()
         else:
             step.set_lr(float(optimizer.param_groups[0]['lr']))
         step.set_batch(inp, target, target_weight)
-        step.step(allreduce)
+        nxt = next(it, None)
+        if nxt is not None and tuple(nxt[0].shape) == tuple(inp.shape):
+            step.teacher_async(nxt[0])                 # teacher runs one batch ahead, overlapping this student step
+        elif nxt is not None:
+            pass                                       # shape change: the new step object primes itself above
+        step.student_step(allreduce)
         if i % config.PRINT_FREQ == 0:
-            step.flush()
             pose, kd, loss = step.losses()                    # the only host sync of the loop
             n = inp.size(0)
             pose_losses.update(pose, n); kd_pose_losses.update(kd, n); losses.update(loss, n)
