@@ -15,6 +15,8 @@ int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
 int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st);
@@ -103,13 +105,17 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
 int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->x && a->w && a->bias && a->y, "stem: null pointer");
     FPD_REQUIRE(a->P == (a->H + 6 - 7) / 2 + 1 && a->Q == (a->W + 6 - 7) / 2 + 1, "stem: bad output size");
-    int rc = fpd_stem_forward_launch(*a, (hipStream_t)stream);
+    int rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_forward_mfma_launch(*a, (hipStream_t)stream);
+    if (rc == 1) rc = fpd_stem_forward_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
 
 int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->x && a->dy && a->dw, "stem wgrad: null pointer");
-    int rc = fpd_stem_wgrad_launch(*a, (hipStream_t)stream);
+    int rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_wgrad_mfma_launch(*a, (hipStream_t)stream);
+    if (rc == 1) rc = fpd_stem_wgrad_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
 

@@ -14,11 +14,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "mfma_frag.h"
 
 namespace {
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 template <typename T>
 struct WFrag;
@@ -30,13 +28,7 @@ struct WFrag<bf16_t> {
     // tile: pixel-major [pixel][LD]; returns the 32(ch) x 16(pixel) operand: lane L -> channel ch0 + (L&31), pixels
     // pix0 + 8*(L>>5) .. +7
     static __device__ __forceinline__ frag_t load(const bf16_t* tile, int LD, int pix0, int ch0, int lane) {
-        const int g = lane >> 4, s = lane & 15;
-        const bf16_t* p = tile + (pix0 + 8 * (g >> 1) + (s >> 2)) * LD + ch0 + 16 * (g & 1) + 4 * (s & 3);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * LD));
-        union { struct { s16x4 a, b; } h; frag_t f; } u;
-        u.h.a = lo; u.h.b = hi;
-        return u.f;
+        return tr_frag_bf16(tile, LD, pix0, ch0, lane);
     }
     static __device__ __forceinline__ void mma(const frag_t& a, const frag_t& b, f32x16& acc) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);

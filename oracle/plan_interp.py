@@ -113,8 +113,9 @@ def run_wgrad(A, op):
 
 
 def run_stem_fwd(A, op):
-    img = A.view(op.image)
-    wt = A.view(op.w).permute(0, 3, 1, 2)         # [K,7,7,3] -> [K,3,7,7]
+    # bf16 build: the MFMA stem multiplies bf16-rounded image and weights (fp32 accumulate); fp32 build: exact fp32
+    img = _rnd(A, A.view(op.image))
+    wt = _rnd(A, A.view(op.w)).permute(0, 3, 1, 2)         # [K,7,7,3] -> [K,3,7,7]
     y = F.conv2d(img, wt, A.view(op.bias), stride=2, padding=3).permute(0, 2, 3, 1)
     y = _rnd(A, y)
     if op.out_stats is not None:
@@ -123,7 +124,7 @@ def run_stem_fwd(A, op):
 
 
 def run_stem_wgrad(A, op):
-    img = A.view(op.image)
+    img = _rnd(A, A.view(op.image))
     dy = _act(A, op.dy).permute(0, 3, 1, 2)
     K = dy.shape[1]
     dw = torch.nn.grad.conv2d_weight(img, (K, 3, 7, 7), dy, stride=2, padding=3)

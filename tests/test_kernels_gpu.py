@@ -217,9 +217,10 @@ def test_conv_wgrad(case, dtype, backend):
     bt.compare(db, label='wgrad dbias', **tol)
 
 
+@pytest.mark.parametrize('backend', [0, 1])
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('case', [(2, 64, 64, 16), (1, 128, 96, 32), (2, 32, 48, 64)])
-def test_stem(case, dtype):
+@pytest.mark.parametrize('case', [(2, 64, 64, 16), (1, 128, 96, 32), (2, 32, 48, 64), (2, 128, 128, 32), (1, 256, 256, 64)])
+def test_stem(case, dtype, backend):
     N, H, W, K = case
     gen = torch.Generator().manual_seed(3 + sum(case))
     bt = Bench(dtype)
@@ -234,7 +235,7 @@ def test_stem(case, dtype):
     db = bt.buf('grad', (K,), torch.zeros(K))
     ops = [G.Op('stem_fwd', image=img, w=w, bias=b, y=y, out_stats=st, dims=(N, H, W, K, P, Q)),
            G.Op('stem_wgrad', image=img, dy=dy, dw=dw, dbias=db, dims=(N, H, W, K, P, Q))]
-    bt.realise().run(ops, 0)
+    bt.realise().run(ops, backend)
     bt.compare(y, label='stem y', **TOL[dtype])
     bt.compare(st, atol=TOL[dtype]['atol'] * N * P * Q, rtol=TOL[dtype]['rtol'], label='stem stats')
     m = N * P * Q
