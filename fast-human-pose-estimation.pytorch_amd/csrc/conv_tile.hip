@@ -60,7 +60,7 @@ struct TapMma<float> {
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 template <typename T, int TN, int BK>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const fpd_conv_t a, const int logW) {
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
     constexpr int LD = BK + 16 / (int)sizeof(T);
@@ -141,53 +141,60 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const fpd_conv_t a, cons
             }
         }
     };
+    // a thread always stages the same VEC channels of a chunk (256 % VPR == 0): BN coefficients live in registers
+    const int cvh = (tid & (VPR - 1)) * VEC;
+    const float relu_lo = a.bn.relu ? 0.f : -3.4e38f;
     auto halo_store = [&](int c0) {
+        float psc[VEC], psh[VEC];
+        if (a.bn.mode != FPD_BN_NONE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { psc[e] = s_scale[c0 + cvh + e]; psh[e] = s_shift[c0 + cvh + e]; }
+        }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             const int v = tid + i * 256;
             if (v < nvtot) {
                 const int hr = v >> (logW + LOG_VPR);
-                const int rem = v & ((W << LOG_VPR) - 1);
-                const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
+                const int j = (v & ((W << LOG_VPR) - 1)) >> LOG_VPR;
                 uint4 val = rh[i];
                 if (a.bn.mode != FPD_BN_NONE) {
                     float f[VEC];
                     DT<T>::unpack(val, f);
-                    const bool ok = (hmask >> i) & 1u;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const float t = bn_act(f[e], s_scale[c0 + cv + e], s_shift[c0 + cv + e], a.bn.relu);
-                        f[e] = ok ? t : 0.f;
-                    }
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[e], psh[e]), relu_lo);
                     val = DT<T>::pack(f);
+                    if (!((hmask >> i) & 1u)) val = make_uint4(0, 0, 0, 0);      // rows outside the tensor stay exactly zero
                 }
-                *reinterpret_cast<uint4*>(sH + (hr * WP + j + pad) * LD + cv) = val;
+                *reinterpret_cast<uint4*>(sH + (hr * WP + j + pad) * LD + cvh) = val;
             }
         }
     };
-    int b_row[NVB], b_col[NVB];
+    int b_loff[NVB];
+    int b_goff[NVB];
     bool b_ok[NVB];
 #pragma unroll
     for (int i = 0; i < NVB; ++i) {
         const int v = tid + i * 256;
-        b_row[i] = v >> LOG_VPR;
-        b_col[i] = (v & (VPR - 1)) * VEC;
-        b_ok[i] = (v < NVB_TOT) && (n0 + b_row[i] < K);
+        const int row = v >> LOG_VPR, col = (v & (VPR - 1)) * VEC;
+        b_loff[i] = row * LD + col;
+        b_ok[i] = (v < NVB_TOT) && (n0 + row < K);
+        b_goff[i] = (n0 + row) * (R * R) * C + col;                  // + tap*C + c0 (wave-uniform) per tile
     }
     uint4 rb[NVB];
     const int RS = R * R;
     auto b_load = [&](int tap, int c0) {
+        const int toff = tap * C + c0;
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             rb[i] = make_uint4(0, 0, 0, 0);
-            if (b_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(w + ((size_t)(n0 + b_row[i]) * RS + tap) * C + c0 + b_col[i]);
+            if (b_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(w + (b_goff[i] + toff));
         }
     };
     auto b_store = [&](int buf) {
         T* dst = sB + buf * BNT * LD;
 #pragma unroll
         for (int i = 0; i < NVB; ++i)
-            if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(dst + b_row[i] * LD + b_col[i]) = rb[i];
+            if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(dst + b_loff[i]) = rb[i];
     };
 
     f32x16 acc[TN];
