@@ -91,7 +91,11 @@ __device__ __forceinline__ void conv_epi_tables(const fpd_conv_t& a, const int n
 
 // Vectorised epilogue (needs K % VEC == 0): the accumulators go through an fp32 LDS staging tile (64 rows at a
 // time) so that residual / epi_x are read and y is written as 16-byte vectors along the channel axis, each thread
-// owning one channel-vector column (its per-channel statistics stay in registers until the end).
+// owning one channel-vector column.  Statistics: a thread sums SHIFTED values (v - c, c = its first value of that
+// channel) in fp32 over its <= 16 rows -- no cancellation because c is within a few sigma of the mean -- and converts
+// to the global {sum v, sum v^2} in fp64 once (sum v = S1 + n c, sum v^2 = S2 + 2 c S1 + n c^2); everything after
+// that (cross-thread, cross-block) is fp64.  The BN-backward sums {dz, dz*xhat} have no such cancellation and are
+// accumulated in fp32 per thread, fp64 beyond.
 //   stage: >= 64*(32*TN+4) floats, 16-byte aligned; s_red: >= 4*32*TN*2 doubles (may alias stage)
 template <typename T, int TN>
 __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32x16* acc, const int m0, const int n0,
@@ -109,10 +113,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
     const bool want_stats = (a.out_stats != nullptr) || bwd;
     float bias[VEC], esc[VEC], esh[VEC], emu[VEC], eis[VEC];
-    double s1[VEC], s2[VEC];
+    float f1[VEC], f2[VEC], cshift[VEC];
+    int nrow = 0;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        s1[e] = 0.0; s2[e] = 0.0;
+        f1[e] = 0.f; f2[e] = 0.f; cshift[e] = 0.f;
         bias[e] = (a.bias != nullptr && kok) ? a.bias[k0 + e] : 0.f;
         esc[e] = esh[e] = emu[e] = eis[e] = 0.f;
         if (bwd) {
@@ -120,6 +125,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             esc[e] = s_epi[t]; esh[e] = s_epi[BNT + t]; emu[e] = s_epi[2 * BNT + t]; eis[e] = s_epi[3 * BNT + t];
         }
     }
+    const float relu_gate = a.epi_bn.relu ? 0.f : -3.4e38f;     // z > gate keeps the gradient
     const int col_l = lane & 31, rhalf = lane >> 5;
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase) {
@@ -152,32 +158,55 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] += bias[e];
+                const uint4 packed = DT<T>::pack(v);
                 if (bwd) {
-                    float xv[VEC];
+                    float xv[VEC], vr[VEC];
                     DT<T>::unpack(*reinterpret_cast<const uint4*>(ex + off), xv);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float z = fmaf(xv[e], esc[e], esh[e]);
-                        v[e] = (!a.epi_bn.relu || z > 0.f) ? v[e] : 0.f;
-                        const double vr = (double)DT<T>::rnd(v[e]);
-                        s1[e] += vr;
-                        s2[e] += vr * (double)((xv[e] - emu[e]) * eis[e]);
+                        v[e] = (z > relu_gate) ? v[e] : 0.f;
                     }
-                } else if (want_stats) {
+                    const uint4 pk = DT<T>::pack(v);
+                    DT<T>::unpack(pk, vr);                  // the stored (rounded) gradient is what gets summed
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const double vr = (double)DT<T>::rnd(v[e]);
-                        s1[e] += vr;
-                        s2[e] += vr * vr;
+                        f1[e] += vr[e];
+                        f2[e] = fmaf(vr[e], (xv[e] - emu[e]) * eis[e], f2[e]);
                     }
+                    *reinterpret_cast<uint4*>(y + off) = pk;
+                } else {
+                    if (want_stats) {
+                        float vr[VEC];
+                        DT<T>::unpack(packed, vr);
+                        if (nrow == 0) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) cshift[e] = vr[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float d = vr[e] - cshift[e];
+                            f1[e] += d;
+                            f2[e] = fmaf(d, d, f2[e]);
+                        }
+                        ++nrow;
+                    }
+                    *reinterpret_cast<uint4*>(y + off) = packed;
                 }
-                *reinterpret_cast<uint4*>(y + off) = DT<T>::pack(v);
             }
         }
     }
     if (want_stats) {
+        double s1[VEC], s2[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
+            if (bwd) {
+                s1[e] = (double)f1[e]; s2[e] = (double)f2[e];
+            } else {
+                const double c = (double)cshift[e], n = (double)nrow;
+                s1[e] = (double)f1[e] + n * c;
+                s2[e] = (double)f2[e] + 2.0 * c * (double)f1[e] + n * c * c;
+            }
 #pragma unroll
             for (int o = CVN; o < 64; o <<= 1) {
                 s1[e] += __shfl_xor(s1[e], o, 64);
