@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--backend', default='mfma', choices=['mfma', 'naive'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='launch kernel by kernel instead of replaying hipGraphs')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=2)
     args = ap.parse_args()
@@ -111,6 +112,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step.run_pipelined(1, allreduce)                 # one eager step (sets one-time kernel attributes) before capture
+    if not args.no_graphs:
+        step.enable_graphs()
     step.run_pipelined(args.warmup, allreduce)
     barrier()
     l = R.lib()
@@ -141,6 +145,7 @@ def main():
         'config': {'workload': 'configs[1]: hourglass student S=4 F=128 + teacher S=8 F=256, 256x256, batch %d/GPU, '
                                'fused FPD step incl. Adam, teacher forward one batch ahead on a 2nd stream%s' % (B, ' + RCCL all-reduce' if world > 1 else ''),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,
+                   'launch': 'eager' if args.no_graphs else 'hipGraph replay per phase',
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
         'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'traffic': None,

@@ -188,6 +188,7 @@ class GraphInstance:
         self.low = Lowering(self.A, self.dtype)
         self.plan = R.Plan()
         self.rng = {}
+        self.graphs = {}
         self._image_ext = image
         self._finalized = False
         self.mid_ops = []          # IR ops between fwd and bwd (loss)
@@ -237,8 +238,23 @@ class GraphInstance:
         return self
 
     def run(self, name, stream=None):
+        gid = self.graphs.get(name)
+        if gid is not None:
+            self.plan.replay(gid, stream)
+            return
         b, e = self.rng[name]
         self.plan.run(b, e, stream)
+
+    def capture(self, names, cap_stream):
+        """Capture plan ranges into hipGraphs (one per name) on `cap_stream` (a non-default stream; the ranges must
+        already have run eagerly once so one-time kernel attributes are set).  run(name) then replays the graph:
+        the ~1 700 launches of a step stop costing host time one by one."""
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cap_stream):
+            for n in names:
+                b, e = self.rng[n]
+                self.graphs[n] = self.plan.capture(b, e, C.c_void_p(cap_stream.cuda_stream))
+        torch.cuda.synchronize()
 
     def image(self):
         return self.A.tensor('image').view(self.g.N, 3, self.g.H, self.g.W)
@@ -395,6 +411,13 @@ class FusedFPDStep:
         else:
             s.run('adam')
         self._k_s += 1
+
+    def enable_graphs(self):
+        """Replay every phase as a hipGraph from now on (call after at least one eager step)."""
+        cap = torch.cuda.Stream(device=self.student.state.device)
+        if self.teacher is not None:
+            self.teacher.capture(['fwd'], cap)
+        self.student.capture(['prep', 'fwd', 'mid', 'mid1', 'bwd', 'adam'], cap)
 
     def step(self, allreduce=None):
         """Un-pipelined iteration on the batch given to set_batch(): teacher forward, then the student step."""

@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--graph', action='store_true', help='time a hipGraph of --iters copies (device-side time per launch)')
     args = ap.parse_args()
     dtype = R.BF16 if args.dtype == 'bf16' else R.F32
     dev = torch.device('cuda:0')
@@ -74,17 +75,33 @@ def main():
                       out_stats=G.Buf('stats', 2 * C, (2, K)) if bnm == 'train' else None, bn=bn, epi='plain', epi_x=None,
                       epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
         plan = R.Plan()
-        plan.add(*low.op(op))
+        reps = args.iters if args.graph else 1
+        for _ in range(reps):
+            plan.add(*low.op(op))
         st = R.current_stream()
         for _ in range(3):
             plan.run(0, 1, st)
         torch.cuda.synchronize()
         e0, e1 = l.fpd_event_create(), l.fpd_event_create()
-        l.fpd_event_record(e0, st)
-        for _ in range(args.iters):
-            plan.run(0, 1, st)
-        l.fpd_event_record(e1, st)
-        ms = l.fpd_event_elapsed_ms(e0, e1) / args.iters
+        if args.graph:
+            import ctypes
+            cs = torch.cuda.Stream()
+            with torch.cuda.stream(cs):
+                gid = plan.capture(0, reps, ctypes.c_void_p(cs.cuda_stream))
+            torch.cuda.synchronize()
+            plan.replay(gid, st)
+            torch.cuda.synchronize()
+            l.fpd_event_record(e0, st)
+            for _ in range(5):
+                plan.replay(gid, st)
+            l.fpd_event_record(e1, st)
+            ms = l.fpd_event_elapsed_ms(e0, e1) / (5 * reps)
+        else:
+            l.fpd_event_record(e0, st)
+            for _ in range(args.iters):
+                plan.run(0, 1, st)
+            l.fpd_event_record(e1, st)
+            ms = l.fpd_event_elapsed_ms(e0, e1) / args.iters
         fl = 2.0 * N * P * Q * K * C * Rr * Rr
         print('%-22s %s %8.1f us  %7.1f TFLOP/s' % (name, 'wgrad' if args.wgrad else 'conv ', ms * 1e3, fl / ms / 1e9), flush=True)
 
