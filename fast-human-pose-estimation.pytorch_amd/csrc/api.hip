@@ -12,6 +12,8 @@ int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
+int fpd_wgrad_tile_partials(const fpd_wgrad_t& a);
+int fpd_wreduce_launch(const fpd_wreduce_entry_t* table, int n, int64_t max_elems, hipStream_t st);
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
@@ -66,7 +68,7 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t);
 #undef SZ
     return -1;
 }
@@ -97,8 +99,19 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_tile_launch(*a, st);
+    FPD_REQUIRE(rc != 1 || a->partial == nullptr, "wgrad: partial slabs requested for a shape fpd_wgrad_num_partials() reports 0 for");
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
+    return rc ? rc : check_launch();
+}
+
+int fpd_wgrad_num_partials(const fpd_wgrad_t* a) {
+    if (!a || g_fpd_backend != FPD_BACKEND_MFMA) return 0;
+    return fpd_wgrad_tile_partials(*a);
+}
+
+int fpd_wgrad_reduce(const fpd_wreduce_entry_t* t, int32_t n, int64_t max_elems, fpd_stream_t stream) {
+    int rc = fpd_wreduce_launch(t, n, max_elems, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
 
@@ -197,7 +210,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_LOSS: want = sizeof(fpd_loss_t); break;
         case FPD_OP_ADAM: want = sizeof(fpd_adam_t); break;
         case FPD_OP_MEMSET: want = sizeof(fpd_memset_t); break;
-        case FPD_OP_WPREP: case FPD_OP_BNUPD: want = sizeof(fpd_table_t); break;
+        case FPD_OP_WPREP: case FPD_OP_BNUPD: case FPD_OP_WREDUCE: want = sizeof(fpd_table_t); break;
         default: return fpd_fail(-2, "plan_add: unknown op %d", op);
     }
     FPD_REQUIRE((size_t)bytes == want, "plan_add: op %d expects %zu bytes of args, got %lld", op, want, (long long)bytes);
@@ -222,6 +235,7 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
         case FPD_OP_WPREP:
             return fpd_weight_prep((const fpd_wprep_entry_t*)o.u.table.table, o.u.table.n, o.u.table.max_elems, o.u.table.dtype, s);
         case FPD_OP_BNUPD: return fpd_bn_update_running((const fpd_bnupd_entry_t*)o.u.table.table, o.u.table.n, s);
+        case FPD_OP_WREDUCE: return fpd_wgrad_reduce((const fpd_wreduce_entry_t*)o.u.table.table, o.u.table.n, o.u.table.max_elems, s);
     }
     return fpd_fail(-2, "run_op: unknown op %d", o.type);
 }

@@ -47,9 +47,9 @@ struct WFrag<float> {
     }
 };
 
-template <typename T, int R>
+template <typename T, int R, int TP>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int logW, const int ctiles,
-                                                         const int mtiles) {
+                                                         const int mtiles, const int dbg) {
     using WF = WFrag<T>;
     constexpr int VEC = DT<T>::VEC;
     constexpr int CW = 128 / (int)sizeof(T);          // channels per tile row: 64 (bf16) / 32 (fp32) = 128 bytes
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     constexpr int KC1 = CW / 32, KC = KC1 * KC1;      // (ki,ci) sub-tiles of 32x32: 4 / 1
     constexpr int KSTEP = WF::KSTEP;
     constexpr int BLK = 512, NW = BLK / 64;           // 8 waves: two per SIMD, sharing one staged tile
-    constexpr int NVH = 2048 / BLK, NVD = 128 * 8 / BLK;   // halo / dy 16-byte vectors per thread
+    constexpr int NVH = 2048 / BLK, NVD = TP * 8 / BLK;    // halo / dy 16-byte vectors per thread (TP pixels per tile)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, C = a.C, K = a.K, pad = a.pad;
     const int GR = a.N * H;
-    const int nrows = 128 >> logW, hrows = nrows + R - 1, WP = W + R - 1;
+    const int nrows = TP >> logW, hrows = nrows + R - 1, WP = W + R - 1;
     const int HP = hrows * WP;
     const int kt = blockIdx.y / ctiles, ct = blockIdx.y - kt * ctiles;
     const int k0 = kt * CW, c0 = ct * CW;
@@ -74,14 +74,14 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     float* s_shift = s_scale + CW;
     T* sH = reinterpret_cast<T*>(s_shift + CW);
     T* sD = sH + HP * LD;
-    T* sZ = sD + 128 * LD;                              // 16 all-zero pixels: operand of taps whose row is outside the image
+    T* sZ = sD + TP * LD;                              // 16 all-zero pixels: operand of taps whose row is outside the image
     const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
 
     // zero the whole tile region once: border columns, unused channel columns and ragged rows then stay zero
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
-        const int nv = (HP + 128 + 16) * LD / VEC;
+        const int nv = (HP + TP + 16) * LD / VEC;
         for (int v = tid; v < nv; v += BLK) *reinterpret_cast<uint4*>(sH + v * VEC) = z;
     }
     if (a.bn.mode != FPD_BN_NONE) {
@@ -95,13 +95,15 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     // ---- this wave's accumulator slots: u = wave + 4*i -> (tap, ki, ci) ----
     constexpr int RS = R * R, NT = RS * KC;
     constexpr int NS = (NT + NW - 1) / NW;    // accumulator slots per wave: 5 (3x3 bf16), 2 (3x3 fp32), 1 (1x1)
+    constexpr bool KSPLIT = (NT <= NW / 2);   // 1x1: fewer tiles than waves -> the two wave groups split the pixel steps
+    const int kgrp = KSPLIT ? wave / (NW / 2) : 0;
     const int kc = wave % KC;                 // fixed per wave (KC in {1,4})
     const int ki = kc / KC1, ci = kc % KC1;
     int tap_off[NS], slot_r[NS];
     bool slot_on[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int u = wave + NW * i;
+        const int u = (KSPLIT ? wave % (NW / 2) : wave) + NW * i;
         slot_on[i] = u < NT;
         const int tap = slot_on[i] ? u / KC : 0;      // idle slots compute on tap 0 and are never flushed
         const int r = tap / R, s = tap - r * R;
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     float bsum = 0.f;
     const bool do_bias = (a.dbias != nullptr) && ct == 0;
     const int bch = tid % CW, bpart = tid / CW;        // bias partial sums: channel, pixel part (BLK/CW parts)
-    constexpr int BPARTS = BLK / CW, BPIX = 128 / BPARTS;
+    constexpr int BPARTS = BLK / CW, BPIX = TP / BPARTS;
 
     // ---- staging: everything that does not depend on the pixel tile is computed once per thread ----
     const int nvh = (hrows << logW) * vpr_c;          // halo vectors of one tile
-    const int nvd = 128 * vpr_k;
+    const int nvd = TP * vpr_k;
     int h_goff[NVH], h_loff[NVH], h_row[NVH];         // global element offset (tile 0), LDS element offset, halo row
     int d_goff[NVD], d_loff[NVD];
 #pragma unroll
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     if (tile < mtiles) loads(tile);
     for (; tile < mtiles; tile += gridDim.x) {
         __syncthreads();                    // previous tile consumed (first time: zero fill + tables visible)
-        stores();
+        if (!(dbg & 4)) stores();
         __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < mtiles) loads(next);     // in flight during this tile's MFMAs
+        if (next < mtiles && !(dbg & 8)) loads(next);     // in flight during this tile's MFMAs
         const int g0 = tile * nrows;
         if (do_bias) {
             float s0 = 0.f, s1 = 0.f;
@@ -215,13 +217,14 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
             }
             bsum += s0 + s1;
         }
-#pragma unroll 1
-        for (int pix0 = 0; pix0 < 128; pix0 += KSTEP) {
+        // one k-step = KSTEP pixels: operand fetch (transposing LDS reads) then NS MFMAs.  With many slots (3x3) the
+        // MFMAs of a step cover the next step's LDS latency; with one slot (1x1) several steps are unrolled instead.
+        auto kstep = [&](int pix0) {
             const int ti = pix0 >> logW, j0 = pix0 & (W - 1);
             const int g = g0 + ti;
-            if (g >= GR) break;             // ragged last tile (wave-uniform)
             const int p = g % H;
-            const typename WF::frag_t af = WF::load(sD, LD, pix0, ki * 32, lane);
+            const bool live = g < GR;                       // ragged last tile: rows past the tensor contribute zeros
+            const typename WF::frag_t af = WF::load(live ? sD : sZ, LD, live ? pix0 : 0, ki * 32, lane);
             const T* hbase = sH + (ti * WP + j0) * LD;
             typename WF::frag_t bf[NS];
 #pragma unroll
@@ -231,61 +234,144 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
             }
 #pragma unroll
             for (int i = 0; i < NS; ++i) WF::mma(af, bf[i], acc[i]);
+        };
+        if (dbg & 2) continue;
+        if (NS == 1) {
+#pragma unroll 4
+            for (int pix0 = (KSPLIT ? kgrp * KSTEP : 0); pix0 < TP; pix0 += (KSPLIT ? 2 : 1) * KSTEP) kstep(pix0);
+        } else {
+#pragma unroll 1
+            for (int pix0 = 0; pix0 < TP; pix0 += KSTEP) kstep(pix0);
         }
     }
 
     // ---- flush ----
+    if (dbg & 1) return;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (slot_on[i]) {
-            const int u = wave + NW * i;
+            const int u = (KSPLIT ? wave % (NW / 2) : wave) + NW * i;
             const int tap = u / KC;
             const int c = c0 + ci * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = k0 + ki * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (k < K && c < C) atomicAdd(a.dw + ((size_t)k * RS + tap) * C + c, acc[i][e]);
+                if (k < K && c < C) {
+                    const size_t idx = ((size_t)k * RS + tap) * C + c;
+                    if (a.partial != nullptr) {
+                        // one slab per persistent block (two when the wave groups split the pixel steps)
+                        float* slab = a.partial + (size_t)(blockIdx.x * (KSPLIT ? 2 : 1) + kgrp) * a.partial_stride;
+                        slab[idx] = acc[i][e];
+                    } else {
+                        atomicAdd(a.dw + idx, acc[i][e]);
+                    }
+                }
             }
         }
     }
-    if (do_bias && bch < kn) atomicAdd(a.dbias + k0 + bch, bsum);
+    if (do_bias) {
+        // block-level reduction of the per-thread partial sums first: every block of the grid targets the SAME K
+        // addresses, and same-address device atomics serialise (it was ~60 % of the 1x1 kernel time)
+        float* s_bias = reinterpret_cast<float*>(sD);
+        __syncthreads();
+        if (tid < CW) s_bias[tid] = 0.f;
+        __syncthreads();
+        atomicAdd(&s_bias[bch], bsum);
+        __syncthreads();
+        if (tid < kn) {
+            if (a.partial != nullptr) {          // bias partials live behind the weight slab: [K*R*S*C .. +K)
+                const size_t boff = (size_t)K * RS * C + k0 + tid;
+                a.partial[(size_t)(blockIdx.x * (KSPLIT ? 2 : 1)) * a.partial_stride + boff] = s_bias[tid];
+                if (KSPLIT) a.partial[(size_t)(blockIdx.x * 2 + 1) * a.partial_stride + boff] = 0.f;
+            } else {
+                atomicAdd(a.dbias + k0 + tid, s_bias[tid]);
+            }
+        }
+    }
 }
 
-template <typename T, int R>
-int launch_wt(const fpd_wgrad_t& a, int logW, hipStream_t st) {
+struct WtGrid { int logW, tp, gx, gy, ctiles, mtiles, slabs; };
+
+// single source of truth for the launch geometry (also tells the caller how many partial slabs will be written)
+bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
+    if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 16 || (a.W & (a.W - 1)) != 0) return false;
+    if (a.C % 16 != 0 || a.K % 16 != 0) return false;
+    g.logW = 0;
+    while ((1 << g.logW) < a.W) ++g.logW;
+    const int vec = a.dtype == FPD_BF16 ? 8 : 4, cw = a.dtype == FPD_BF16 ? 64 : 32;
+    const int hrows = (128 >> g.logW) + a.R - 1;
+    if (hrows * a.W * (std::min(a.C, cw) / vec) > 2048) return false;
+    // 1x1: no halo, HBM-bound -> 256-pixel tiles double the bytes in flight per block and halve the barriers
+    g.tp = (a.R == 1 && a.N * a.H * a.W >= 256 * 256 && 256 % a.W == 0) ? 256 : 128;
+    g.mtiles = cdiv(a.N * a.H * a.W, g.tp);
+    g.ctiles = cdiv(a.C, cw);
+    g.gy = cdiv(a.K, cw) * g.ctiles;
+    // persistent blocks, each flushing its whole accumulator once: 3x3 = 147 KB per block -> few blocks;
+    // 1x1 = 16 KB per block and HBM-bound -> enough blocks to keep every CU streaming
+    int target = (a.R == 1) ? 256 : 128;
+    if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
+    g.gx = std::max(1, std::min(g.mtiles, cdiv(target, g.gy)));
+    const int nt = a.R * a.R * (cw / 32) * (cw / 32);
+    g.slabs = g.gx * (nt <= 4 ? 2 : 1);          // KSPLIT kernels write one slab per wave group
+    return true;
+}
+
+template <typename T, int R, int TP>
+int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     constexpr int CW = 128 / (int)sizeof(T);
     constexpr int LD = CW + 16 / (int)sizeof(T);
-    const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
-    const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + 128 + 16) * LD * sizeof(T);
+    const int nrows = TP >> g.logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
+    const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + TP + 16) * LD * sizeof(T);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
-    const int mtiles = cdiv(a.N * a.H * a.W, 128);
-    const int ktiles = cdiv(a.K, CW), ctiles = cdiv(a.C, CW);
-    const int gy = ktiles * ctiles;
-    int target = 128;   // persistent blocks: each flushes its whole accumulator with device-scope atomics once
-    if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
-    const int gx = std::max(1, std::min(mtiles, cdiv(target, gy)));
-    hipLaunchKernelGGL((wgrad_tile_kernel<T, R>), dim3(gx, gy), dim3(512), lds, st, a, logW, ctiles, mtiles);
+    static const int dbg = getenv("FPD_WGRAD_DBG") ? atoi(getenv("FPD_WGRAD_DBG")) : 0;   // ablation bits (timing experiments only)
+    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.logW, g.ctiles, g.mtiles, dbg);
     return 0;
+}
+
+// dw[i] += sum_b partial[b*stride + i]: second stage of the weight-gradient reduction for a table of convolutions
+__global__ __launch_bounds__(256) void wreduce_kernel(const fpd_wreduce_entry_t* table) {
+    const fpd_wreduce_entry_t e = table[blockIdx.y];
+    const int64_t n4 = e.n >> 2;                 // n is a multiple of 4 (K*R*S*C with C % 16 == 0)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(e.dw + 4 * i);
+        const float* p = e.partial + 4 * i;
+#pragma unroll 4
+        for (int b = 0; b < e.count; ++b) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)b * e.stride);
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+        *reinterpret_cast<f32x4*>(e.dw + 4 * i) = acc;
+    }
 }
 
 }  // namespace
 
 // returns 1 when the shape is outside this kernel's domain
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
-    if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return 1;
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 16 || (a.W & (a.W - 1)) != 0) return 1;
-    if (a.C % 16 != 0 || a.K % 16 != 0) return 1;
-    int logW = 0;
-    while ((1 << logW) < a.W) ++logW;
-    const int hrows = (128 >> logW) + a.R - 1;
-    const int vec = a.dtype == FPD_BF16 ? 8 : 4, cw = a.dtype == FPD_BF16 ? 64 : 32;
-    if (hrows * a.W * (std::min(a.C, cw) / vec) > 2048) return 1;
-    if (a.R == 3) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 3>(a, logW, st) : launch_wt<float, 3>(a, logW, st);
-    return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1>(a, logW, st) : launch_wt<float, 1>(a, logW, st);
+    WtGrid g;
+    if (!wt_grid(a, g)) return 1;
+    if (a.partial != nullptr && a.partial_stride < (int64_t)a.K * a.R * a.S * a.C + a.K)
+        return fpd_fail(-2, "wgrad: partial_stride %lld smaller than weight + bias", (long long)a.partial_stride);
+    if (a.R == 3) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 3, 128>(a, g, st) : launch_wt<float, 3, 128>(a, g, st);
+    if (g.tp == 256) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 256>(a, g, st) : launch_wt<float, 1, 256>(a, g, st);
+    return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 128>(a, g, st) : launch_wt<float, 1, 128>(a, g, st);
+}
+
+int fpd_wgrad_tile_partials(const fpd_wgrad_t& a) {
+    WtGrid g;
+    return wt_grid(a, g) ? g.slabs : 0;
+}
+
+int fpd_wreduce_launch(const fpd_wreduce_entry_t* table, int n, int64_t max_elems, hipStream_t st) {
+    if (n <= 0) return 0;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems / 4 + 255) / 256, 64)), (unsigned)n);
+    hipLaunchKernelGGL(wreduce_kernel, grid, dim3(256), 0, st, table);
+    return 0;
 }

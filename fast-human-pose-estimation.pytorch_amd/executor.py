@@ -62,6 +62,8 @@ class Lowering:
     def __init__(self, arenas, dtype):
         self.A, self.dtype = arenas, dtype
         self.keep = []          # device tables that must outlive the plan
+        self.use_partials = False
+        self.partials, self.partial_elems = [], 0
 
     def bn(self, bn):
         s = R.BnT()
@@ -95,7 +97,38 @@ class Lowering:
         p = self.A.ptr
         s.x, s.dy, s.dw, s.dbias = p(_abuf(op.x)), p(_abuf(op.dy)), p(op.dw), p(op.dbias)
         s.bn = self.bn(op.bn)
+        s.partial, s.partial_stride = None, 0
+        if self.use_partials:
+            # two-stage reduction instead of device-scope atomics: ask the library how many slabs this launch writes
+            n = R.lib().fpd_wgrad_num_partials(C.byref(s))
+            if n > 0:
+                numel = op.dw.numel
+                stride = (numel + s.K + 63) // 64 * 64          # weight slab + bias partials
+                self.partials.append([s, op.dw, numel, stride, n, self.partial_elems, op.dbias])
+                self.partial_elems += n * stride
         return R.OP_WGRAD, s
+
+    def finish_partials(self):
+        """Allocate the slab workspace, patch the recorded wgrad structs, return the reduce op (or None)."""
+        if not self.partials:
+            return None
+        ws = torch.empty(self.partial_elems, dtype=torch.float32, device=self.A.device)
+        self.keep.append(ws)
+        ents, mx = [], 0
+        for s, dw, numel, stride, n, off, dbias in self.partials:
+            s.partial = ws.data_ptr() + 4 * off
+            s.partial_stride = stride
+            e = R.WreduceEntryT()
+            e.partial, e.dw, e.n, e.stride, e.count = s.partial, self.A.ptr(dw), numel, stride, n
+            ents.append(e)
+            if dbias is not None:
+                e = R.WreduceEntryT()
+                e.partial, e.dw, e.n, e.stride, e.count = s.partial + 4 * numel, self.A.ptr(dbias), s.K, stride, n
+                ents.append(e)
+            mx = max(mx, numel)
+        t = R.TableT()
+        t.table, t.n, t.dtype, t.max_elems = self._table(ents, R.WreduceEntryT), len(ents), self.dtype, mx
+        return R.OP_WREDUCE, t
 
     def stem(self, op):
         s = R.StemT()
@@ -230,9 +263,13 @@ class GraphInstance:
         if self.train:
             b = len(p)
             p.add(*self.low.memset('grad'))
-            for op in g.bwd:
-                if op.kind != 'seed':
-                    p.add(*self.low.op(op))
+            self.low.use_partials = True
+            lowered = [self.low.op(op) for op in g.bwd if op.kind != 'seed']
+            red = self.low.finish_partials()          # patches the wgrad structs with their slab pointers
+            for code, st in lowered:
+                p.add(code, st)
+            if red is not None:
+                p.add(*red)                           # dw += sum of slabs, all convolutions in one launch
             self.rng['bwd'] = (b, len(p))
         self._finalized = True
         return self

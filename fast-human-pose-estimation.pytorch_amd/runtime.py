@@ -15,7 +15,8 @@ EPI_PLAIN, EPI_BNRELU_BWD = 0, 1
 BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
-(OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD) = range(10)
+(OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
+ OP_WREDUCE) = range(11)
 MAX_STACKS = 8
 MAXC = 512
 
@@ -37,7 +38,7 @@ class ConvT(C.Structure):
 class WgradT(C.Structure):
     _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('K', _i32), ('R', _i32), ('S', _i32),
                 ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('x', _vp), ('dy', _vp),
-                ('dw', _vp), ('dbias', _vp), ('bn', BnT)]
+                ('dw', _vp), ('dbias', _vp), ('bn', BnT), ('partial', _vp), ('partial_stride', _i64)]
 
 
 class StemT(C.Structure):
@@ -74,6 +75,10 @@ class BnupdEntryT(C.Structure):
                 ('count', _f64), ('momentum', _f32), ('C', _i32)]
 
 
+class WreduceEntryT(C.Structure):
+    _fields_ = [('partial', _vp), ('dw', _vp), ('n', _i64), ('stride', _i64), ('count', _i32), ('_pad', _i32)]
+
+
 class MemsetT(C.Structure):
     _fields_ = [('ptr', _vp), ('bytes', _i64)]
 
@@ -84,12 +89,15 @@ class TableT(C.Structure):
 
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
-            'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT}
+            'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
+            'fpd_wreduce_entry_t': WreduceEntryT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'fpd_conv_forward': (C.c_int, [C.POINTER(ConvT), _vp]),
     'fpd_conv_wgrad': (C.c_int, [C.POINTER(WgradT), _vp]),
+    'fpd_wgrad_num_partials': (C.c_int, [C.POINTER(WgradT)]),
+    'fpd_wgrad_reduce': (C.c_int, [_vp, _i32, _i64, _vp]),
     'fpd_stem_forward': (C.c_int, [C.POINTER(StemT), _vp]),
     'fpd_stem_wgrad': (C.c_int, [C.POINTER(StemT), _vp]),
     'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),

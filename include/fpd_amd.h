@@ -85,6 +85,11 @@ typedef struct {
     float* dw;             /* [K][R][S][C] fp32 */
     float* dbias;          /* [K] or NULL */
     fpd_bn_t bn;           /* forward prologue, recomputed */
+    /* optional two-stage reduction: instead of flushing its accumulator into dw with device-scope atomics, persistent
+     * block b stores it to partial + b*partial_stride (layout of dw); fpd_wgrad_reduce() sums the slabs afterwards.
+     * The number of slabs the kernel will write for these dimensions is fpd_wgrad_num_partials() (0 = atomics only). */
+    float* partial;
+    int64_t partial_stride; /* floats between slabs, >= K*R*S*C + K (bias partials sit behind the weights) */
 } fpd_wgrad_t;
 
 /* Stem: Conv2d(3, K, 7, stride 2, pad 3) (hourglass.py:116,172) reading the fp32 NCHW image. */
@@ -179,9 +184,17 @@ typedef struct {
     double count; float momentum; int32_t C;
 } fpd_bnupd_entry_t;
 
+/* dw[i] += sum_{b < count} partial[b*stride + i], i < n : second stage of the weight-gradient reduction, one
+ * launch for a table of convolutions. */
+typedef struct {
+    const float* partial; float* dw; int64_t n; int64_t stride; int32_t count; int32_t _pad;
+} fpd_wreduce_entry_t;
+
 /* ---- single-op entry points (asynchronous on `stream`) ---- */
 int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream);
 int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
+int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writes when a->partial is set */
+int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, int64_t max_elems, fpd_stream_t stream);
 int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream);
 int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream);
 int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream);
@@ -200,7 +213,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 /* ---- execution plan: a recorded list of the ops above, replayed with one call ---- */
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
-    FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9
+    FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

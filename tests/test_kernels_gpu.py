@@ -57,15 +57,25 @@ class Bench:
             self.gpu.view(b).copy_(v)
         return self
 
-    def run(self, ops, backend):
+    def run(self, ops, backend, partials=False):
         PI.run(self.cpu, ops)
         low = E.Lowering(self.gpu, self.dtype)
         plan = R.Plan()
+        prev = R.set_backend(backend)
+        low.use_partials = partials          # two-stage weight-gradient reduction (slabs + fpd_wgrad_reduce)
+        lowered = []
         for op in ops:
             if op.kind == 'wprep':
-                plan.add(*low.wprep([(e['w'], e.get('w_fwd'), e.get('w_bwd')) for e in op.entries]))
+                lowered.append(low.wprep([(e['w'], e.get('w_fwd'), e.get('w_bwd')) for e in op.entries]))
             else:
-                plan.add(*low.op(op))
+                lowered.append(low.op(op))
+        red = low.finish_partials()
+        for code, st in lowered:
+            plan.add(code, st)
+        if red is not None:
+            plan.add(*red)
+        self.n_partial_ops = len(low.partials)
+        R.set_backend(prev)
         prev = R.set_backend(backend)
         try:
             plan.run(0, len(plan))
@@ -190,7 +200,7 @@ WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), 
                (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True)]
 
 
-@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('backend', BACKENDS + ['partials'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', WGRAD_CASES)
 def test_conv_wgrad(case, dtype, backend):
@@ -210,7 +220,11 @@ def test_conv_wgrad(case, dtype, backend):
         xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
         bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
     op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
-    bt.realise().run([op], backend)
+    if backend == 'partials':          # default dispatch with the two-stage (slab + reduce) flush instead of atomics
+        bt.realise().run([op], 0, partials=True)
+        assert bt.n_partial_ops == (1 if W >= 16 and (W & (W - 1)) == 0 else 0)
+    else:
+        bt.realise().run([op], backend)
     m = N * P * Q
     tol = dict(atol=2e-4 + 1e-6 * m, rtol=2e-4) if dtype == 0 else dict(atol=2e-2 + 2e-5 * m, rtol=3e-2)
     bt.compare(dw, label='wgrad dw %s' % (case,), **tol)
