@@ -78,8 +78,11 @@ __device__ __forceinline__ void bn_coef(const fpd_bn_t& bn, int c, int C, double
                                         float& shift, float& mean, float& invstd) {
     double m, var;
     if (bn.mode == FPD_BN_TRAIN) {
-        m = bn.stats[c] / count;
-        var = bn.stats[C + c] / count - m * m;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < FPD_STATS_REPLICAS; ++r) { s1 += bn.stats[r * 2 * C + c]; s2 += bn.stats[r * 2 * C + C + c]; }
+        m = s1 / count;
+        var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
     } else {
         m = (double)bn.running_mean[c];
@@ -119,6 +122,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// replica of a [R][2][C] statistics buffer this block adds into
+__device__ __forceinline__ int stats_replica() { return (int)((blockIdx.x + blockIdx.y * gridDim.x) % FPD_STATS_REPLICAS); }
+// sum over replicas of element i of a [R][2][C] buffer
+__device__ __forceinline__ double stats_sum(const double* st, int C, int i) {
+    double s = 0.0;
+#pragma unroll 4
+    for (int r = 0; r < FPD_STATS_REPLICAS; ++r) s += st[r * 2 * C + i];
+    return s;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -63,7 +63,7 @@ __device__ __forceinline__ void conv_epilogue(const fpd_conv_t& a, const f32x16*
             if (lane < 32) { s_red[(wave * BNT + tn * 32 + lane) * 2 + 0] = t1; s_red[(wave * BNT + tn * 32 + lane) * 2 + 1] = t2; }
         }
         __syncthreads();
-        double* st = bwd ? a.epi_stats : a.out_stats;
+        double* st = (bwd ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
             if (k < K) {
@@ -222,7 +222,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             }
         }
         __syncthreads();
-        double* st = bwd ? a.epi_stats : a.out_stats;
+        double* st = (bwd ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
             if (k < K) {

@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
             const float z = fmaf(xv, s_epi[0][k], s_epi[1][k]);
             v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
             const float vr = DT<T>::rnd(v);
-            atomicAdd(a.epi_stats + k, (double)vr);
-            atomicAdd(a.epi_stats + K + k, (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k])));
+            atomicAdd(a.epi_stats + stats_replica() * 2 * K + k, (double)vr);
+            atomicAdd(a.epi_stats + stats_replica() * 2 * K + K + k, (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k])));
         } else if (a.out_stats) {
             const float vr = DT<T>::rnd(v);
-            atomicAdd(a.out_stats + k, (double)vr);
-            atomicAdd(a.out_stats + K + k, (double)(vr * vr));
+            atomicAdd(a.out_stats + stats_replica() * 2 * K + k, (double)vr);
+            atomicAdd(a.out_stats + stats_replica() * 2 * K + K + k, (double)(vr * vr));
         }
         DT<T>::st(y + idx, v);
     }

@@ -47,13 +47,14 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
             bn_coef(a.bn, c, C, cnt, sc, sh, mu, is);
             if (OP == FPD_EW_BN_BWD_APPLY) {
                 s_t0[c] = a.bn.gamma[c] * is;                 // gamma * invstd
-                s_t1[c] = (float)(a.bstats[c] / cnt);         // mean(dz)
-                s_t2[c] = (float)(a.bstats[C + c] / cnt);     // mean(dz * xhat)
+                const double b1 = stats_sum(a.bstats, C, c), b2 = stats_sum(a.bstats, C, C + c);
+                s_t1[c] = (float)(b1 / cnt);                  // mean(dz)
+                s_t2[c] = (float)(b2 / cnt);                  // mean(dz * xhat)
                 s_t3[c] = mu;
                 s_is[c] = is;
                 if (blockIdx.x == 0) {   // gradients of the BN affine parameters fall out of the two sums
-                    if (a.dgamma) a.dgamma[c] = (float)a.bstats[C + c];
-                    if (a.dbeta) a.dbeta[c] = (float)a.bstats[c];
+                    if (a.dgamma) a.dgamma[c] = (float)b2;
+                    if (a.dbeta) a.dbeta[c] = (float)b1;
                 }
             } else {
                 s_t0[c] = sc; s_t1[c] = sh; s_t2[c] = mu; s_t3[c] = is;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
             for (int j = 0; j < VEC; ++j) { atomicAdd(&s_sum[0][cv + j], acc1[j]); atomicAdd(&s_sum[1][cv + j], acc2[j]); }
         }
         __syncthreads();
-        double* dst = STATS ? a.out_stats : a.bstats;
+        double* dst = (STATS ? a.out_stats : a.bstats) + (size_t)stats_replica() * 2 * C;
         for (int c = tid; c < C; c += 256) {
             atomicAdd(dst + c, s_sum[0][c]);
             atomicAdd(dst + C + c, s_sum[1][c]);
@@ -187,7 +188,11 @@ int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     const int VP = a.C / VEC, PB = 256 / VP;
     const bool half = (OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_MAXPOOL_BWD || OP == FPD_EW_SUMPOOL);
     const int npix = a.N * (half ? a.H / 2 : a.H) * (half ? a.W / 2 : a.W);
-    const int grid = std::max(1, std::min(cdiv(npix, PB), 2048));
+    // grid-stride kernels: ops that end with per-channel statistics atomics get few, long-lived blocks -- every block
+    // adds into the SAME [2][C] buffer and same-address device atomics serialise (~12 ns each)
+    const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
+                                                                                                   : OP == FPD_EW_BNRELU_BWD_R;
+    const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
     hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }

@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void wprep_kernel(const fpd_wprep_entry_t* tab
 __global__ __launch_bounds__(256) void bnupd_kernel(const fpd_bnupd_entry_t* table) {
     const fpd_bnupd_entry_t e = table[blockIdx.x];
     for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-        const double mean = e.stats[c] / e.count;
-        double var = e.stats[e.C + c] / e.count - mean * mean;
+        const double mean = stats_sum(e.stats, e.C, c) / e.count;
+        double var = stats_sum(e.stats, e.C, e.C + c) / e.count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double unb = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
         e.running_mean[c] = (float)((1.0 - e.momentum) * (double)e.running_mean[c] + e.momentum * mean);

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const fpd_stem_t a) {
             const int py = ty0 + p / TW, px = tx0 + p % TW;
             if (py < P && px < Q) { const double v = (double)buf[p * LDO + tid]; s1 += v; s2 += v * v; }
         }
-        atomicAdd(a.out_stats + tid, s1);
-        atomicAdd(a.out_stats + K + tid, s2);
+        atomicAdd(a.out_stats + stats_replica() * 2 * K + tid, s1);
+        atomicAdd(a.out_stats + stats_replica() * 2 * K + K + tid, s2);
     }
 }
 

@@ -303,7 +303,7 @@ class GraphInstance:
         assert self.train
         torch.cuda.synchronize()
         for bn in self.g.bns:
-            st = self.A.view(bn.stats)
+            st = self.A.view(bn.stats).sum(0)
             mean = st[0] / bn.count
             var = (st[1] / bn.count - mean * mean).clamp_min(0) * (bn.count / max(bn.count - 1, 1))
             self.A.view(bn.rmean).copy_(mean.float())

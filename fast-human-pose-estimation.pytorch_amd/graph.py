@@ -16,6 +16,7 @@ from collections import OrderedDict
 
 BN_EPS = 1e-5        # torch default, hourglass.py:18
 BN_MOMENTUM = 0.1    # hourglass.py:10
+STATS_REPLICAS = 4   # include/fpd_amd.h FPD_STATS_REPLICAS: statistics buffers are [R][2][C]
 
 
 class Buf:
@@ -227,8 +228,8 @@ class HourglassGraph:
 
     def _stats(self, C, name=''):
         off = self.stats_size
-        self.stats_size += 2 * C
-        return Buf('stats', off, (2, C), name)
+        self.stats_size += STATS_REPLICAS * 2 * C
+        return Buf('stats', off, (STATS_REPLICAS, 2, C), name)
 
     def _bn(self, name, C):
         g = self.p

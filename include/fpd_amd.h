@@ -28,6 +28,10 @@ extern "C" {
 typedef void* fpd_stream_t; /* hipStream_t */
 
 enum { FPD_F32 = 0, FPD_BF16 = 1 };
+/* Every per-channel statistics buffer (BN forward {sum, sumsq}; BN backward {sum dz, sum dz*xhat}) holds
+ * FPD_STATS_REPLICAS independent partial copies: layout [R][2][C] fp64.  Producer block b adds into replica b % R
+ * (thousands of blocks adding into ONE address serialise at ~12 ns per atomic); consumers sum the replicas. */
+#define FPD_STATS_REPLICAS 4
 enum { FPD_BN_NONE = 0, FPD_BN_TRAIN = 1, FPD_BN_EVAL = 2 };
 enum { FPD_EPI_PLAIN = 0, FPD_EPI_BNRELU_BWD = 1 };
 enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1, FPD_BACKEND_MFMA_GENERIC = 2 };
@@ -43,7 +47,7 @@ typedef struct {
     int32_t relu;          /* apply ReLU after the affine (hourglass.py:28) */
     float eps;
     int32_t _pad;
-    const double* stats;   /* TRAIN: [2][C] sum, sum of squares over N*H*W */
+    const double* stats;   /* TRAIN: [R][2][C] sum, sum of squares over N*H*W (R = FPD_STATS_REPLICAS) */
     const float* gamma;    /* [C] */
     const float* beta;     /* [C] */
     const float* running_mean; /* EVAL: [C] */
@@ -69,11 +73,11 @@ typedef struct {
     const float* bias;     /* [K] or NULL */
     const void* residual;  /* [N,P,Q,K] or NULL (may alias y) */
     void* y;
-    double* out_stats;     /* [2][K] += {sum y, sum y^2} or NULL */
+    double* out_stats;     /* [R][2][K] += {sum y, sum y^2} or NULL */
     fpd_bn_t bn;           /* prologue on x (mode NONE = raw x) */
     const void* epi_x;     /* BNRELU_BWD: forward tensor normalised by epi_bn, [N,P,Q,K] */
     fpd_bn_t epi_bn;       /* BNRELU_BWD: its (train-mode) BN */
-    double* epi_stats;     /* BNRELU_BWD: [2][K] += {sum dz, sum dz*xhat} */
+    double* epi_stats;     /* BNRELU_BWD: [R][2][K] += {sum dz, sum dz*xhat} */
 } fpd_conv_t;
 
 /* Weight + bias gradient of the same conv (autograd of hourglass.py convs): dw[K][R][S][C] +=
@@ -99,7 +103,7 @@ typedef struct {
     const float* w;        /* [K][7][7][3] fp32 */
     const float* bias;     /* [K] */
     void* y;               /* [N,P,Q,K] */
-    double* out_stats;     /* [2][K] or NULL */
+    double* out_stats;     /* [R][2][K] or NULL */
     const void* dy;        /* wgrad: [N,P,Q,K] */
     float* dw;             /* wgrad: [K][7][7][3] */
     float* dbias;          /* wgrad: [K] */
@@ -127,8 +131,8 @@ typedef struct {
     const void* dy;
     const void* add;       /* optional accumulate source (may alias y) */
     void* y;
-    double* out_stats;     /* [2][C] or NULL */
-    double* bstats;        /* BN-backward sums [2][C] */
+    double* out_stats;     /* [R][2][C] or NULL */
+    double* bstats;        /* BN-backward sums [R][2][C] */
     float* dgamma;         /* BN_BWD_APPLY: optional [C] <- sum dz*xhat (grad of BN weight) */
     float* dbeta;          /* BN_BWD_APPLY: optional [C] <- sum dz      (grad of BN bias) */
     fpd_bn_t bn;
@@ -179,7 +183,7 @@ typedef struct {
 /* Running-statistics update of train-mode BNs after a forward (torch: momentum 0.1, unbiased
  * variance; hourglass.py:10).  One launch for a table. */
 typedef struct {
-    const double* stats;   /* [2][C] */
+    const double* stats;   /* [R][2][C] */
     float* running_mean; float* running_var; int64_t* num_batches_tracked;
     double count; float momentum; int32_t C;
 } fpd_bnupd_entry_t;

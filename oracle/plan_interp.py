@@ -38,7 +38,7 @@ class Arenas:
 def _bn_coef(A, bn):
     gamma, beta = A.view(bn.gamma).double(), A.view(bn.beta).double()
     if bn.mode == 'train':
-        st = A.view(bn.stats)
+        st = A.view(bn.stats).sum(0)              # [R][2][C] replicas -> [2][C]
         mean = st[0] / bn.count
         var = (st[1] / bn.count - mean * mean).clamp_min(0)
     else:
@@ -62,7 +62,7 @@ def _rnd(A, v):
 
 
 def _stats_add(A, buf, v):          # v: [N,H,W,C] fp32 already rounded to storage precision
-    st = A.view(buf)
+    st = A.view(buf)[0]                          # the interpreter accumulates into replica 0 of [R][2][C]
     vd = v.double()
     st[0] += vd.sum((0, 1, 2))
     st[1] += (vd * vd).sum((0, 1, 2))
@@ -94,7 +94,7 @@ def run_conv(A, op):
         if op.epi_bn.relu:
             y = torch.where(z > 0, y, torch.zeros_like(y))
         yr = _rnd(A, y).double()
-        st = A.view(op.epi_stats)
+        st = A.view(op.epi_stats)[0]
         st[0] += yr.sum((0, 1, 2))
         st[1] += (yr * ((xv - mean) * invstd).double()).sum((0, 1, 2))
     elif op.out_stats is not None:
@@ -145,14 +145,14 @@ def run_ew(A, op):
         z = torch.addcmul(shift, x, scale)
         dz = torch.where(z > 0, dy, torch.zeros_like(dy)) if op.bn.relu else dy
         dzr = _rnd(A, dz).double()
-        st = A.view(op.bstats)
+        st = A.view(op.bstats)[0]
         st[0] += dzr.sum((0, 1, 2))
         st[1] += (dzr * ((x - mean) * invstd).double()).sum((0, 1, 2))
         _store(A, op.y, dz)
     elif name == 'bn_bwd_apply':
         x, dz = _act(A, op.x), _act(A, op.dy)
         _, _, mean, invstd = _bn_coef(A, op.bn)
-        st = A.view(op.bstats)
+        st = A.view(op.bstats).sum(0)
         m1, m2 = (st[0] / op.bn.count).float(), (st[1] / op.bn.count).float()
         g = A.view(op.bn.gamma)
         out = (g * invstd) * (dz - m1 - ((x - mean) * invstd) * m2)
@@ -195,7 +195,7 @@ def run_ew(A, op):
 
 def run_bnupd(A, op, momentum=0.1):
     for bn in op.bns:
-        st = A.view(bn.stats)
+        st = A.view(bn.stats).sum(0)
         mean = st[0] / bn.count
         var = (st[1] / bn.count - mean * mean).clamp_min(0)
         unb = var * bn.count / (bn.count - 1) if bn.count > 1 else var

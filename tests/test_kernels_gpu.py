@@ -87,6 +87,8 @@ class Bench:
         b = b.buf if isinstance(b, G.Act) else b
         c = self.cpu.view(b).double()
         g = self.gpu.view(b).cpu().double()
+        if b.arena == 'stats':              # replicated statistics: only the sum over replicas is defined
+            c, g = c.sum(0), g.sum(0)
         assert torch.isfinite(g).all(), label + ': non-finite values'
         err = (c - g).abs()
         tol = atol + rtol * c.abs()
@@ -110,9 +112,14 @@ def make_bn(bench, gen, C, mode, name='bn', relu=True, stats_from=None):
     return bn
 
 
-def tensor_stats(x):   # x [N,H,W,C] -> [2,C] fp64
+RS = 4    # FPD_STATS_REPLICAS: statistics buffers are [R][2][C]; the CPU side keeps everything in replica 0
+
+
+def tensor_stats(x):   # x [N,H,W,C] -> [R,2,C] fp64 (replica 0 filled)
     xd = x.double()
-    return torch.stack([xd.sum((0, 1, 2)), (xd * xd).sum((0, 1, 2))])
+    out = torch.zeros(RS, 2, x.shape[-1], dtype=torch.float64)
+    out[0] = torch.stack([xd.sum((0, 1, 2)), (xd * xd).sum((0, 1, 2))])
+    return out
 
 
 TOL = {0: dict(atol=2e-4, rtol=2e-4), 1: dict(atol=3e-2, rtol=3e-2)}
@@ -153,8 +160,8 @@ def test_conv_forward(case, dtype, backend):
         bn.count = N * H * W
         if bn_mode == 'train':
             xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
-            bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
-    ostats = bt.buf('stats', (2, K), torch.zeros(2, K, dtype=torch.float64)) if use_stats else None
+            bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(xs))
+    ostats = bt.buf('stats', (RS, 2, K), torch.zeros(RS, 2, K, dtype=torch.float64)) if use_stats else None
     op = G.Op('conv', x=x, w=w, wkey='w', bias=bias, bkey='b', residual=res, y=y, out_stats=ostats, bn=bn, epi='plain',
               epi_x=None, epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
     bt.realise().run([op], backend)
@@ -185,8 +192,8 @@ def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
     bn = make_bn(bt, gen, C, 'train')
     bn.count = N * H * W
     xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
-    bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
-    bst = bt.buf('stats', (2, C), torch.zeros(2, C, dtype=torch.float64))
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(xs))
+    bst = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
     ops = [G.Op('wprep', entries=[{'w': wm, 'w_fwd': None, 'w_bwd': wb}]),
            G.Op('conv', x=dy, w=wb, wkey='w', bias=None, bkey=None, residual=prev, y=prev, out_stats=None, bn=None,
                 epi='bnrelu_bwd', epi_x=x, epi_bn=bn, epi_stats=bst, dims=(N, P, Q, K, C, Rr, Rr, 1, Rr - 1 - pad, H, W))]
@@ -218,7 +225,7 @@ def test_conv_wgrad(case, dtype, backend):
         bn = make_bn(bt, gen, C, 'train')
         bn.count = N * H * W
         xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
-        bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+        bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(xs))
     op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
     if backend == 'partials':          # default dispatch with the two-stage (slab + reduce) flush instead of atomics
         bt.realise().run([op], 0, partials=True)
@@ -243,7 +250,7 @@ def test_stem(case, dtype, backend):
     w = bt.buf('param', (K, 7, 7, 3), rnd(gen, K, 7, 7, 3, scale=1 / np.sqrt(147)))
     b = bt.buf('param', (K,), 0.1 * rnd(gen, K))
     y = bt.act((N, P, Q, K), None, 'y')
-    st = bt.buf('stats', (2, K), torch.zeros(2, K, dtype=torch.float64))
+    st = bt.buf('stats', (RS, 2, K), torch.zeros(RS, 2, K, dtype=torch.float64))
     dy = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K, scale=0.1), 'dy')
     dw = bt.buf('grad', (K, 7, 7, 3), torch.zeros(K, 7, 7, 3))
     db = bt.buf('grad', (K,), torch.zeros(K))
@@ -275,10 +282,10 @@ def test_elementwise_ops(shape, dtype):
     bn = make_bn(bt, gen, C, 'train')
     bn.count = N * H * W
     xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
-    bn.stats = bt.buf('stats', (2, C), tensor_stats(xs))
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(xs))
 
     def z():
-        return bt.buf('stats', (2, C), torch.zeros(2, C, dtype=torch.float64))
+        return bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
     y1, y2, y3, y4, y5, y6, y7, y8 = [bt.act(s, None, 'y%d' % i) for i, s in enumerate(
         [shape, shape, shape, half, shape, shape, half, shape])]
     s1, s4, s6, bst = z(), z(), z(), z()
@@ -397,7 +404,7 @@ def test_bn_update_running_and_layout_and_cast():
     x = rnd(gen, 2, 5, 5, C) + 1
     bn = make_bn(bt, gen, C, 'train')
     bn.count = 50
-    bn.stats = bt.buf('stats', (2, C), tensor_stats(x))
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x))
     bt.realise().run([G.Op('bnupd', bns=[bn])], 0)
     bt.compare(bn.rmean, atol=1e-6, rtol=1e-6, label='running_mean')
     bt.compare(bn.rvar, atol=1e-6, rtol=1e-6, label='running_var')

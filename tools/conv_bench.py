@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--no-stats', action='store_true', help='ablation: do not accumulate output statistics')
     ap.add_argument('--graph', action='store_true', help='time a hipGraph of --iters copies (device-side time per launch)')
     args = ap.parse_args()
     dtype = R.BF16 if args.dtype == 'bf16' else R.F32
@@ -44,7 +45,7 @@ def main():
         A = E.Arenas(dev, dtype)
         P, Q = H + 2 * pad - Rr + 1, W + 2 * pad - Rr + 1
         sizes = {'act': N * H * W * C + 2 * N * P * Q * K + 256, 'wlp': K * Rr * Rr * C, 'param': 4 * max(C, K) + K * Rr * Rr * C,
-                 'rstat': 2 * C, 'stats': 2 * C + 2 * K, 'nbt': 4, 'grad': K * Rr * Rr * C + K}
+                 'rstat': 2 * C, 'stats': G.STATS_REPLICAS * (2 * C + 2 * K), 'nbt': 4, 'grad': K * Rr * Rr * C + K}
         for n_, s_ in sizes.items():
             A.alloc(n_, s_)
         A.t['act'].copy_(torch.randn(A.t['act'].numel(), generator=gen).to(A.t['act'].dtype))
@@ -63,16 +64,16 @@ def main():
                       G.Buf('rstat', C, (C,)), G.Buf('nbt', 0, ()))
             bn.count = N * H * W
             if bnm == 'train':
-                bn.stats = G.Buf('stats', 0, (2, C))
+                bn.stats = G.Buf('stats', 0, (G.STATS_REPLICAS, 2, C))
                 xv = A.view(x.buf).double()
-                A.view(bn.stats).copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
+                A.view(bn.stats)[0].copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
         low = E.Lowering(A, dtype)
         if args.wgrad:
             op = G.Op('wgrad', x=x, dy=y, dw=G.Buf('grad', 0, (K, Rr, Rr, C)), dbias=G.Buf('grad', K * Rr * Rr * C, (K,)), bn=bn,
                       dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
         else:
             op = G.Op('conv', x=x, w=G.Buf('wlp', 0, (K, Rr, Rr, C)), wkey='w', bias=G.Buf('param', 2 * C, (K,)), bkey='b', residual=r, y=y,
-                      out_stats=G.Buf('stats', 2 * C, (2, K)) if bnm == 'train' else None, bn=bn, epi='plain', epi_x=None,
+                      out_stats=G.Buf('stats', G.STATS_REPLICAS * 2 * C, (G.STATS_REPLICAS, 2, K)) if (bnm == 'train' and not args.no_stats) else None, bn=bn, epi='plain', epi_x=None,
                       epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
         plan = R.Plan()
         reps = args.iters if args.graph else 1

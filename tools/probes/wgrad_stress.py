@@ -8,7 +8,7 @@ iters = int(sys.argv[8]) if len(sys.argv) > 8 else 300
 dev = torch.device('cuda:0'); dtype = R.BF16
 A = E.Arenas(dev, dtype)
 M = N * H * W
-for n_, s_ in {'act': M * C + M * K + 128, 'param': 2 * C, 'rstat': 2 * C, 'stats': 2 * C, 'nbt': 4, 'grad': K * Rr * Rr * C + K}.items():
+for n_, s_ in {'act': M * C + M * K + 128, 'param': 2 * C, 'rstat': 2 * C, 'stats': 2 * C * G.STATS_REPLICAS, 'nbt': 4, 'grad': K * Rr * Rr * C + K}.items():
     A.alloc(n_, s_)
 g = torch.Generator().manual_seed(0)
 A.t['act'].copy_(torch.randn(A.t['act'].numel(), generator=g).to(torch.bfloat16))
@@ -16,8 +16,8 @@ A.t['param'][:C] = 1.0
 x = G.Act((N, H, W, C)); x.buf = G.Buf('act', 0, x.shape)
 dy = G.Act((N, H, W, K)); dy.buf = G.Buf('act', M * C, dy.shape)
 bn = G.BN('bn', 'train', C, G.Buf('param', 0, (C,)), G.Buf('param', C, (C,)), G.Buf('rstat', 0, (C,)), G.Buf('rstat', C, (C,)), G.Buf('nbt', 0, ()))
-bn.count = M; bn.stats = G.Buf('stats', 0, (2, C))
-xv = A.view(x.buf).double(); A.view(bn.stats).copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
+bn.count = M; bn.stats = G.Buf('stats', 0, (G.STATS_REPLICAS, 2, C))
+xv = A.view(x.buf).double(); A.view(bn.stats)[0].copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
 op = G.Op('wgrad', x=x, dy=dy, dw=G.Buf('grad', 0, (K, Rr, Rr, C)), dbias=G.Buf('grad', K * Rr * Rr * C, (K,)), bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, H, W))
 plan = R.Plan(); plan.add(*E.Lowering(A, dtype).op(op))
 res = []
