@@ -2,6 +2,7 @@
 // hipGraph capture/replay, HIP-event timing helpers.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -181,10 +182,20 @@ struct fpd_op {
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
+struct fpd_sched {                       // per-op multi-lane schedule (fpd_plan_set_schedule)
+    int32_t lane = 0;
+    bool record = false;                 // some op of another lane waits for this one
+    hipEvent_t done = nullptr;
+    std::vector<int32_t> waits;
+};
 struct fpd_plan {
     std::vector<fpd_op> ops;
+    std::vector<fpd_sched> sched;
     std::vector<hipGraphExec_t> graphs;
     std::vector<hipGraph_t> graph_defs;
+    hipStream_t lanes[FPD_MAX_LANES] = {};      // [0] unused: lane 0 is the caller's stream
+    hipEvent_t lane_done[FPD_MAX_LANES] = {};
+    hipEvent_t fork = nullptr;
 };
 
 fpd_plan* fpd_plan_create(void) { return new fpd_plan(); }
@@ -192,6 +203,12 @@ void fpd_plan_destroy(fpd_plan* p) {
     if (!p) return;
     for (auto g : p->graphs) (void)hipGraphExecDestroy(g);
     for (auto g : p->graph_defs) (void)hipGraphDestroy(g);
+    for (auto& s : p->sched) if (s.done) (void)hipEventDestroy(s.done);
+    for (int l = 0; l < FPD_MAX_LANES; ++l) {
+        if (p->lanes[l]) (void)hipStreamDestroy(p->lanes[l]);
+        if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
+    }
+    if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
 }
 int fpd_plan_size(const fpd_plan* p) { return p ? (int)p->ops.size() : -1; }
@@ -216,7 +233,21 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
     FPD_REQUIRE((size_t)bytes == want, "plan_add: op %d expects %zu bytes of args, got %lld", op, want, (long long)bytes);
     memcpy(&o.u, args, want);
     p->ops.push_back(o);
+    p->sched.emplace_back();
     return (int)p->ops.size() - 1;
+}
+
+int fpd_plan_set_schedule(fpd_plan* p, int32_t op, int32_t lane, const int32_t* wait_ops, int32_t n_waits) {
+    FPD_REQUIRE(p && op >= 0 && op < (int)p->ops.size(), "plan_set_schedule: bad op index %d", op);
+    FPD_REQUIRE(lane >= 0 && lane < FPD_MAX_LANES, "plan_set_schedule: lane %d outside [0,%d)", lane, FPD_MAX_LANES);
+    FPD_REQUIRE(n_waits >= 0 && (n_waits == 0 || wait_ops != nullptr), "plan_set_schedule: bad wait list");
+    for (int i = 0; i < n_waits; ++i)
+        FPD_REQUIRE(wait_ops[i] >= 0 && wait_ops[i] < op, "plan_set_schedule: op %d may only wait for earlier ops (got %d)", op, wait_ops[i]);
+    fpd_sched& s = p->sched[op];
+    s.lane = lane;
+    s.waits.assign(wait_ops, wait_ops + n_waits);
+    for (int i = 0; i < n_waits; ++i) p->sched[wait_ops[i]].record = true;
+    return 0;
 }
 
 static int run_op(const fpd_op& o, fpd_stream_t s) {
@@ -240,17 +271,64 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
     return fpd_fail(-2, "run_op: unknown op %d", o.type);
 }
 
+static int lane_priority() {            // FPD_LANE_PRIORITY=low|high|normal(default): priority of the side-lane streams
+    static int prio = -1000;
+    if (prio == -1000) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // lo = least urgent (numerically greatest)
+        const char* e = getenv("FPD_LANE_PRIORITY");
+        prio = (e && e[0] == 'l') ? lo : (e && e[0] == 'h') ? hi : 0;
+    }
+    return prio;
+}
+
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     FPD_REQUIRE(p && begin >= 0 && end <= (int)p->ops.size() && begin <= end, "plan_run: bad range [%d,%d)", begin, end);
-    for (int i = begin; i < end; ++i) {
-        int rc = run_op(p->ops[i], stream);
+    hipStream_t main_s = (hipStream_t)stream;
+    bool multi = false;
+    for (int i = begin; i < end; ++i) multi |= p->sched[i].lane != 0;
+    bool used[FPD_MAX_LANES] = {};
+    if (multi) {
+        if (!p->fork) FPD_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+        FPD_CHECK_HIP(hipEventRecord(p->fork, main_s));
+    }
+    int rc = 0;
+    for (int i = begin; i < end && rc == 0; ++i) {
+        fpd_sched& sc = p->sched[i];
+        hipStream_t st = main_s;
+        if (sc.lane != 0) {
+            const int l = sc.lane;
+            if (!p->lanes[l]) {
+                FPD_CHECK_HIP(hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, lane_priority()));
+                FPD_CHECK_HIP(hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));
+            }
+            st = p->lanes[l];
+            if (!used[l]) {                      // fork: the lane starts after everything already queued on `stream`
+                FPD_CHECK_HIP(hipStreamWaitEvent(st, p->fork, 0));
+                used[l] = true;
+            }
+        }
+        for (int32_t w : sc.waits)
+            if (w >= begin && w < end) FPD_CHECK_HIP(hipStreamWaitEvent(st, p->sched[w].done, 0));
+        rc = run_op(p->ops[i], (fpd_stream_t)st);
         if (rc) {
             char tmp[400];
             snprintf(tmp, sizeof(tmp), "%s", g_err);
-            return fpd_fail(rc, "plan op %d (type %d): %s", i, p->ops[i].type, tmp);
+            rc = fpd_fail(rc, "plan op %d (type %d): %s", i, p->ops[i].type, tmp);
+            break;
+        }
+        if (sc.record) {
+            if (!sc.done) FPD_CHECK_HIP(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+            FPD_CHECK_HIP(hipEventRecord(sc.done, st));
         }
     }
-    return 0;
+    // join (also on failure, so that a stream capture in progress can be closed cleanly)
+    for (int l = 1; l < FPD_MAX_LANES; ++l)
+        if (used[l]) {
+            FPD_CHECK_HIP(hipEventRecord(p->lane_done[l], p->lanes[l]));
+            FPD_CHECK_HIP(hipStreamWaitEvent(main_s, p->lane_done[l], 0));
+        }
+    return rc;
 }
 
 int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {

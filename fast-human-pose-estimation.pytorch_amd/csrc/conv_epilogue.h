@@ -89,14 +89,14 @@ __device__ __forceinline__ void conv_epi_tables(const fpd_conv_t& a, const int n
     }
 }
 
-// Vectorised epilogue (needs K % VEC == 0): the accumulators go through an fp32 LDS staging tile (64 rows at a
-// time) so that residual / epi_x are read and y is written as 16-byte vectors along the channel axis, each thread
+// Vectorised epilogue (needs K % VEC == 0): the accumulators go through an fp32 LDS staging tile (all 128 rows
+// at once) so that residual / epi_x are read and y is written as 16-byte vectors along the channel axis, each thread
 // owning one channel-vector column.  Statistics: a thread sums SHIFTED values (v - c, c = its first value of that
 // channel) in fp32 over its <= 16 rows -- no cancellation because c is within a few sigma of the mean -- and converts
 // to the global {sum v, sum v^2} in fp64 once (sum v = S1 + n c, sum v^2 = S2 + 2 c S1 + n c^2); everything after
 // that (cross-thread, cross-block) is fp64.  The BN-backward sums {dz, dz*xhat} have no such cancellation and are
 // accumulated in fp32 per thread, fp64 beyond.
-//   stage: >= 64*(32*TN+4) floats, 16-byte aligned; s_red: >= 4*32*TN*2 doubles (may alias stage)
+//   stage: >= 128*(32*TN+4) floats, 16-byte aligned; s_red: >= 4*32*TN*2 doubles (may alias stage)
 template <typename T, int TN>
 __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32x16* acc, const int m0, const int n0,
                                                   const int M, const float* s_epi, float* stage, double* s_red) {
@@ -127,21 +127,18 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     }
     const float relu_gate = a.epi_bn.relu ? 0.f : -3.4e38f;     // z > gate keeps the gradient
     const int col_l = lane & 31, rhalf = lane >> 5;
+    __syncthreads();                                       // tile region free: every wave is past its last MFMA LDS read
 #pragma unroll
-    for (int phase = 0; phase < 2; ++phase) {
-        __syncthreads();                                   // staging tile free (and, first time, MFMA LDS reads done)
-        if ((wave >> 1) == phase) {
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (wave & 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * rhalf;
-                    stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
-                }
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+            stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
         }
-        __syncthreads();
-        for (int row = row0; row < 64; row += RSTEP) {
-            const int m = m0 + 64 * phase + row;
+    __syncthreads();
+    {
+        for (int row = row0; row < 128; row += RSTEP) {
+            const int m = m0 + row;
             if (m < M && kok) {
                 float v[VEC];
 #pragma unroll

@@ -11,6 +11,7 @@
 //
 // Same contract as conv_mfma_kernel (see conv_mfma.hip / include/fpd_amd.h); replaces the same reference calls.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -60,7 +61,7 @@ struct TapMma<float> {
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 template <typename T, int TN, int BK>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW) {
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW, const int dbg) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
     constexpr int LD = BK + 16 / (int)sizeof(T);
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
             *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
         }
     }
-    bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    if (!(dbg & 8)) bn_fill(a.bn, C, (double)M, s_scale, s_shift);
     conv_epi_tables<BNT>(a, n0, M, s_epi);
 
     // ---- per-lane A addressing: output pixel -> halo row/col; invalid tap rows point at the zero pixels ----
@@ -210,13 +211,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
         const int c0 = ch * BK;
         const bool more = ch + 1 < nchunk;
         __syncthreads();                 // previous chunk fully consumed (and, first time, tables/zero fill visible)
-        halo_store(c0);
+        if (!(dbg & 4)) halo_store(c0);
         b_store(0);
         __syncthreads();
         if (more) halo_load(c0 + BK);    // in flight during all taps of this chunk
         if (RS > 1) b_load(1, c0); else if (more) b_load(0, c0 + BK);
         int r = 0, s = 0;
-        for (int tap = 0; tap < RS; ++tap) {
+        for (int tap = 0; tap < ((dbg & 2) ? 0 : RS); ++tap) {
             const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
             TapMma<T>::template run<TN, BK, LD>(sH + ab + s * LD, sB + (tap & 1) * BNT * LD, lane, acc);
             if (tap + 1 < RS) {
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
             if (++s == R) { s = 0; ++r; }
         }
     }
+    if (dbg & 1) return;
     if (K % VEC == 0) {
         conv_epilogue_vec<T, TN>(a, acc, m0, n0, M, s_epi, stage, s_red);   // starts with a barrier
     } else {
@@ -240,7 +242,7 @@ int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
     constexpr int LD = BK + 16 / (int)sizeof(T);
     const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
     const size_t tile = (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)2 * 32 * TN * LD * sizeof(T);
-    const size_t epi = std::max((size_t)64 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
+    const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile, epi);
     static size_t configured = 0;
     if (lds > configured) {
@@ -251,7 +253,8 @@ int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
     }
     const int M = a.N * a.H * a.W;
     dim3 grid(cdiv(M, 128), cdiv(a.K, 32 * TN));
-    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, logW);
+    static const int dbg = getenv("FPD_CONV_DBG") ? atoi(getenv("FPD_CONV_DBG")) : 0;   // ablation bits (timing experiments only)
+    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, logW, dbg);
     return 0;
 }
 

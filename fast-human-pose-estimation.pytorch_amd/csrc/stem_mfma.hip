@@ -213,7 +213,7 @@ int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     if (!stem_mfma_ok(a, logQ)) return 1;
     const int TN = a.K > 32 ? 2 : 1;
     const size_t tile = (size_t)(128 + 32 * TN) * LDA * sizeof(bf16_t);
-    const size_t lds = std::max(tile, (size_t)64 * (32 * TN + 4) * sizeof(float)) + patch_bytes(logQ);
+    const size_t lds = std::max(tile, (size_t)128 * (32 * TN + 4) * sizeof(float)) + patch_bytes(logQ);
     const int tiles = a.N * a.P * a.Q / 128;
     static bool cfg1 = false, cfg2 = false;
     if (TN == 1) {

@@ -5,11 +5,13 @@ PyTorch is used here only as the HBM allocator, stream provider and RCCL front e
 (torch.distributed); every kernel that touches the data is in csrc/ (libfpd_amd.so).
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import graph as G
 from . import runtime as R
+from .schedule import PhaseSchedule
 
 _EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd_apply': R.EW_BN_BWD_APPLY,
        'maxpool_fwd': R.EW_MAXPOOL_FWD, 'maxpool_bwd': R.EW_MAXPOOL_BWD, 'upadd_fwd': R.EW_UPADD_FWD,
@@ -212,11 +214,15 @@ class GraphInstance:
     graphs 'bwd' (zero parameter gradients, backward ops).  `extra_ops` (e.g. the fused loss) can be spliced
     between fwd and bwd by the trainer before finalize()."""
 
-    def __init__(self, state, cfg, batch, height, width, train, image=None):
+    def __init__(self, state, cfg, batch, height, width, train, image=None, share_weights_with=None):
         self.state, self.train = state, train
+        self._wlp_owner = share_weights_with       # another instance of the same model whose working weights we read
         self.dtype = state.dtype
+        env = os.environ.get
         self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
-                                  num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32))
+                                  num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
+                                  lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
+                                  wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
         self.low = Lowering(self.A, self.dtype)
         self.plan = R.Plan()
@@ -227,14 +233,34 @@ class GraphInstance:
         self.mid_ops = []          # IR ops between fwd and bwd (loss)
         self.mid_native = []       # callables adding native ops for the mid section
 
+    def _schedule(self, name, ir_ops):
+        """Multi-lane schedule of plan range `name`; ir_ops[k] is the IR op behind plan op begin+k (None = barrier)."""
+        b, e = self.rng[name]
+        assert e - b == len(ir_ops), (name, b, e, len(ir_ops))
+        if not self.lanes_enabled or not any(o is not None and o.lane for o in ir_ops):
+            return
+        sch = PhaseSchedule([((o.lane or 0), o.accesses()) if o is not None else (0, None) for o in ir_ops], self.g.n_lanes)
+        for k in range(len(ir_ops)):
+            if sch.lanes[k] or sch.waits[k]:
+                self.plan.set_schedule(b + k, sch.lanes[k], [b + w for w in sch.waits[k]])
+        self.schedules[name] = sch
+
     def finalize(self):
         g = self.g
         ops = g.fwd + self.mid_ops + g.bwd
-        act = G.plan_memory(ops)
+        self.lanes_enabled = os.environ.get('FPD_LANES', '1') != '0'
+        self.schedules = {}
+        # several lanes in flight: do not hand a released block to the very next tensor (false WAR dependencies)
+        delay = int(os.environ.get('FPD_REUSE_DELAY', '400')) if self.lanes_enabled else 0
+        act = G.plan_memory(ops, reuse_delay=delay)
         self.act_elems = act
         self.A.alloc('act', act)
         self.A.alloc('stats', g.stats_size)
-        self.A.alloc('wlp', g.wlp_size)
+        if self._wlp_owner is not None:            # same ParamTable -> same layout of the working-weight arena
+            assert self._wlp_owner.g.wlp_size == g.wlp_size and not self.train
+            self.A.t['wlp'] = self._wlp_owner.A.t['wlp']
+        else:
+            self.A.alloc('wlp', g.wlp_size)
         if self._image_ext is not None:
             self.A.t['image'] = self._image_ext
         else:
@@ -256,6 +282,7 @@ class GraphInstance:
         for op in g.fwd:
             p.add(*self.low.op(op))
         self.rng['fwd'] = (b, len(p))
+        self._schedule('fwd', list(g.fwd))
         b = len(p)
         for fn in self.mid_native:
             fn(p)
@@ -264,13 +291,15 @@ class GraphInstance:
             b = len(p)
             p.add(*self.low.memset('grad'))
             self.low.use_partials = True
-            lowered = [self.low.op(op) for op in g.bwd if op.kind != 'seed']
+            bwd_ir = [op for op in g.bwd if op.kind != 'seed']
+            lowered = [self.low.op(op) for op in bwd_ir]
             red = self.low.finish_partials()          # patches the wgrad structs with their slab pointers
             for code, st in lowered:
                 p.add(code, st)
             if red is not None:
                 p.add(*red)                           # dw += sum of slabs, all convolutions in one launch
             self.rng['bwd'] = (b, len(p))
+            self._schedule('bwd', [None] + bwd_ir + ([None] if red is not None else []))
         self._finalized = True
         return self
 
@@ -323,23 +352,38 @@ class FusedFPDStep:
     No host synchronisation inside; losses are read back only when asked for."""
 
     def __init__(self, student_state, student_cfg, teacher_state, teacher_cfg, batch, height, width, alpha,
-                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1, adam=None):
+                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1, adam=None, teacher_chunks=None):
         dev = student_state.device
         self.dtype = student_state.dtype
         self.alpha, self.world_size = alpha, world_size
         self.B, self.J = batch, student_cfg['J']
         # teacher first: it owns the image buffer; its last-stack map is read in place by the loss kernel
         self.teacher = None
+        self.teachers = []
         self.tmap = [None, None]
         if teacher_state is not None:
             assert teacher_state.dtype == self.dtype
-            self.teacher = GraphInstance(teacher_state, teacher_cfg, batch, height, width, train=False).finalize()
-            self.teacher.run('prep')           # frozen weights: working copies are prepared once
-            nt = self.teacher.g.outputs[-1].numel
-            # the teacher runs one batch ahead on its own stream: its last-stack map is staged in two slots
+            # The frozen teacher normalises with running statistics, so its samples are independent: the batch CAN be cut
+            # into chunks that run as separate op chains on separate streams (teacher_chunks / FPD_TEACHER_CHUNKS).
+            # Measured on MI355X (r01): 1 chunk 15.0 ms/step, 2 chunks 15.0, 4 chunks 17.7 -- beyond three concurrent
+            # streams (teacher, student chain, weight-gradient lane) the step gets slower, so the default is 1.
+            if teacher_chunks is None:
+                teacher_chunks = int(os.environ.get('FPD_TEACHER_CHUNKS', '1'))
+            while batch % teacher_chunks:
+                teacher_chunks -= 1
+            cb = batch // teacher_chunks
+            self.teacher = GraphInstance(teacher_state, teacher_cfg, cb, height, width, train=False).finalize()
+            self.teachers = [self.teacher] + [
+                GraphInstance(teacher_state, teacher_cfg, cb, height, width, train=False,
+                              share_weights_with=self.teacher).finalize() for _ in range(1, teacher_chunks)]
+            self.teacher.run('prep')           # frozen weights: working copies are prepared once, shared by the chunks
+            nt = self.teacher.g.outputs[-1].numel * teacher_chunks
+            # the teacher runs one batch ahead on its own streams: its last-stack map is staged in two slots
             self.tmap = [torch.zeros(nt, dtype=act_torch_dtype(self.dtype), device=dev) for _ in range(2)]
-            self.t_stream = torch.cuda.Stream(device=dev)
+            self.t_streams = [torch.cuda.Stream(device=dev) for _ in range(teacher_chunks)]
+            self.t_stream = self.t_streams[0]
             self.ev_t = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_chunk = [torch.cuda.Event() for _ in range(teacher_chunks)]
         self._k_t = self._k_s = 0
         self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True)
         g = self.student.g
@@ -413,19 +457,27 @@ class FusedFPDStep:
         """Frozen-teacher forward of one batch on the teacher stream.  It may be submitted one batch ahead of the
         student step that consumes it: it then overlaps the previous batch's student forward/backward/Adam (it does
         not depend on the student weights).  `inp` None = reuse the image already in the teacher's buffer."""
-        t = self.teacher
-        if t is None:
+        if self.teacher is None:
             return
         slot = self._k_t % 2
-        T = self.t_stream
-        T.wait_stream(torch.cuda.current_stream())      # inputs staged on the caller's stream; slot free (its loss ran)
-        with torch.cuda.stream(T):
-            if inp is not None:
-                t.image().copy_(inp, non_blocking=True)
-            t.run('fwd')
-            o = t.g.outputs[-1].buf
-            self.tmap[slot].copy_(t.A.tensor('act')[o.off:o.off + o.numel])
-            self.ev_t[slot].record(T)
+        cur = torch.cuda.current_stream()
+        n = len(self.teachers)
+        for k in reversed(range(n)):                    # chunk 0's stream collects the others at the end
+            t, T = self.teachers[k], self.t_streams[k]
+            T.wait_stream(cur)                          # inputs staged on the caller's stream; slot free (its loss ran)
+            with torch.cuda.stream(T):
+                cb = t.g.N
+                if inp is not None:
+                    t.image().copy_(inp[k * cb:(k + 1) * cb], non_blocking=True)
+                t.run('fwd')
+                o = t.g.outputs[-1].buf
+                self.tmap[slot][k * o.numel:(k + 1) * o.numel].copy_(t.A.tensor('act')[o.off:o.off + o.numel])
+                if k:
+                    self.ev_chunk[k].record(T)
+                else:
+                    for j in range(1, n):
+                        T.wait_event(self.ev_chunk[j])
+                    self.ev_t[slot].record(T)
         self._k_t += 1
 
     def student_step(self, allreduce=None):
@@ -452,8 +504,8 @@ class FusedFPDStep:
     def enable_graphs(self):
         """Replay every phase as a hipGraph from now on (call after at least one eager step)."""
         cap = torch.cuda.Stream(device=self.student.state.device)
-        if self.teacher is not None:
-            self.teacher.capture(['fwd'], cap)
+        for t in self.teachers:
+            t.capture(['fwd'], cap)
         self.student.capture(['prep', 'fwd', 'mid', 'mid1', 'bwd', 'adam'], cap)
 
     def step(self, allreduce=None):

@@ -17,6 +17,12 @@ from collections import OrderedDict
 BN_EPS = 1e-5        # torch default, hourglass.py:18
 BN_MOMENTUM = 0.1    # hourglass.py:10
 STATS_REPLICAS = 4   # include/fpd_amd.h FPD_STATS_REPLICAS: statistics buffers are [R][2][C]
+# Multi-lane execution (see schedule.py).  Measured on MI355X/ROCm 7.2: a same-stream kernel->kernel dependency costs
+# ~0.9 us, a cross-stream one (event record + wait) ~10 us, so lanes are coarse: only hourglass up-branches of the
+# LANE_LEVELS largest resolutions get a lane, and weight gradients are issued in batches of WGRAD_BATCH on one lane.
+WGRAD_LANES = 1
+LANE_LEVELS = 0
+WGRAD_BATCH = 24
 
 
 class Buf:
@@ -71,7 +77,36 @@ class Op:
 
     def __init__(self, kind, **kw):
         self.kind = kind
+        self.lane = None               # execution lane (HIP stream) -- stamped by the builder's op lists
         self.__dict__.update(kw)
+
+    def accesses(self):
+        """(reads, writes) as lists of Buf -- what the dependency analysis of the multi-lane schedule sees.
+        None = unknown / whole-arena access: the op is scheduled as a barrier across all lanes."""
+        def b(a):
+            return a.buf if isinstance(a, Act) else a
+
+        def bn_bufs(bn):
+            if bn is None:
+                return []
+            return [bn.gamma, bn.beta] + ([bn.stats] if bn.mode == 'train' else [bn.rmean, bn.rvar])
+        k = self.kind
+        if k == 'conv':
+            rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
+            wr = [b(self.y), self.out_stats, self.epi_stats]
+        elif k == 'wgrad':
+            rd = [b(self.x), b(self.dy)] + bn_bufs(self.bn)
+            wr = [self.dw, self.dbias]
+        elif k == 'stem_fwd':
+            rd, wr = [self.image, self.w, self.bias], [b(self.y), self.out_stats]
+        elif k == 'stem_wgrad':
+            rd, wr = [self.image, b(self.dy)], [self.dw, self.dbias]
+        elif k == 'ew':
+            rd = [b(self.x), b(self.x2), b(self.dy), b(self.add)] + bn_bufs(self.bn)
+            wr = [b(self.y), self.out_stats, self.bstats, self.dgamma, self.dbeta]    # bstats: produced or consumed
+        else:
+            return None
+        return [x for x in rd if x is not None], [x for x in wr if x is not None]
 
     def acts_in(self):
         return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
@@ -129,16 +164,20 @@ class ParamTable:
 # ------------------------------------------------------------------------------------------------
 # memory planning
 # ------------------------------------------------------------------------------------------------
-def plan_memory(ops, align=64):
+def plan_memory(ops, align=64, reuse_delay=0):
     """Assign every Act reachable from `ops` an offset in the 'act' arena by liveness: a tensor is
     allocated at its first appearance and released after the last op that mentions it (persistent
     tensors never).  Outputs of an op are placed before its inputs are released, so an op never
-    overwrites its own inputs unless the IR aliases them on purpose.  Returns the arena size."""
+    overwrites its own inputs unless the IR aliases them on purpose.  `reuse_delay` keeps a released
+    block out of circulation for that many further ops: with several lanes in flight an immediate
+    reuse would chain the new tensor's writer behind the old tensor's last reader on another lane
+    (a false write-after-read dependency); HBM is plentiful, latency is not.  Returns the arena size."""
     last = {}
     for i, op in enumerate(ops):
         for a in op.acts_in() + op.acts_out():
             last[id(a)] = i
     free = []      # list of (off, size)
+    limbo = []     # (release index, off, size) not yet reusable
     top = 0
 
     def alloc(n):
@@ -170,6 +209,9 @@ def plan_memory(ops, align=64):
 
     sizes = {}
     for i, op in enumerate(ops):
+        while limbo and limbo[0][0] + reuse_delay <= i:
+            _, o, n = limbo.pop(0)
+            release(o, n)
         for a in op.acts_in() + op.acts_out():
             if a.buf is None:
                 o, n = alloc(a.numel)
@@ -181,8 +223,21 @@ def plan_memory(ops, align=64):
                 continue
             seen.add(id(a))
             if last[id(a)] == i and not a.persistent and id(a) in sizes:
-                release(a.buf.off, sizes.pop(id(a)))
+                limbo.append((i, a.buf.off, sizes.pop(id(a))))
     return top
+
+
+class _OpList(list):
+    """Op list that stamps the builder's current lane on every op appended without one."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.owner = owner
+
+    def append(self, op):
+        if op.lane is None:
+            op.lane = self.owner._lane
+        super().append(op)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -192,7 +247,7 @@ class HourglassGraph:
     """Op lists for one (model, batch shape, train|eval) instance."""
 
     def __init__(self, params, num_feats, num_stacks, num_joints, batch, height, width, train, num_blocks=1,
-                 depth=4, wlp_is_master=True):
+                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None):
         self.p = params
         self.F, self.S, self.J = num_feats, num_stacks, num_joints
         self.N, self.H, self.W = batch, height, width
@@ -201,7 +256,12 @@ class HourglassGraph:
         self.stats_size = 0
         self.wlp_size = 0
         self.wfwd, self.wbwd = {}, {}
-        self.fwd, self.bwd = [], []
+        self._lane = 0                         # lane 0 = the caller's stream; 1..depth = hourglass up-branches
+        self.lane_levels = LANE_LEVELS if lane_levels is None else lane_levels
+        self.wgrad_batch = WGRAD_BATCH if wgrad_batch is None else wgrad_batch
+        self._wg_pending = []
+        self.n_lanes = 1 + depth + WGRAD_LANES
+        self.fwd, self.bwd = _OpList(self), _OpList(self)
         self.bns = []                          # train-mode BNs in forward order (running-stat update table)
         self.image = Buf('image', 0, (batch, 3, height, width), 'image')
         self.outputs = []
@@ -305,7 +365,13 @@ class HourglassGraph:
         """hourglass.py:80-92."""
         q = '%s%d.' % (p, n - 1)
         nb = self.num_blocks
+        # the up-branch is independent of the whole lower hourglass (a long chain of small, launch-latency-bound
+        # kernels): it gets a lane of its own per level, so the two overlap on the GPU
+        outer = self._lane
+        if n > self.depth - self.lane_levels:
+            self._lane = n
         up1 = self.residual_seq(x, q + '0.', nb)
+        self._lane = outer
         low = self.maxpool(x, q + 'pool')
         low = self.residual_seq(low, q + '1.', nb)
         if n > 1:
@@ -349,18 +415,24 @@ class HourglassGraph:
 
     # ---- backward construction ----
     def _contribute(self, t):
-        """(add_src, out) for an op that writes out = add_src + <its contribution to dL/dt>."""
-        if t.grad is None:
-            t.grad = Act(t.shape, 'd:' + t.name)
-            return None, t.grad
-        return t.grad, t.grad
+        """(add_src, out) for an op that writes out = add_src + <its contribution to dL/dt>.  Gradient tensors are
+        never modified once written (the sum goes to a fresh tensor): deferred readers -- the batched weight-gradient
+        kernels, ops on other lanes -- always see the value the sequential semantics gave them."""
+        prev = t.grad
+        t.grad = Act(t.shape, 'd:' + t.name)
+        return prev, t.grad
 
     def _contribute_identity(self, t, g):
         if t.grad is None:
-            t.grad = g                      # alias: g is final, later contributions accumulate in place
+            t.grad = g                      # alias: g is final and immutable
         else:
-            self.bwd.append(Op('ew', op='add', dims=t.shape, x=t.grad, x2=g, y=t.grad, dy=None, add=None,
-                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None))
+            prev = t.grad
+            t.grad = Act(t.shape, 'd:' + t.name)
+            self.bwd.append(Op('ew', op='add', dims=t.shape, x=prev, x2=g, y=t.grad, dy=None, add=None,
+                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None, lane=self._home(t)))
+
+    def _home(self, t):
+        return t.producer.lane if t.producer is not None and t.producer.lane is not None else 0
 
     def _bn_backward_contribution(self, x, bn, make_dgrad):
         """Route a gradient through the fused BN+ReLU prologue of tensor x.  `make_dgrad(dz, add, bstats)`
@@ -378,9 +450,11 @@ class HourglassGraph:
         pend['left'] -= 1
         if pend['left'] == 0:
             add, out = self._contribute(x)
+            # x's gradient is consumed on the lane of x's producer: finishing it there keeps a side lane's last hop
+            # off the main chain (main -> side -> main would cost two cross-stream dependencies)
             self.bwd.append(Op('ew', op='bn_bwd_apply', dims=x.shape, x=x, x2=None, dy=pend['dz'], add=add, y=out,
                                out_stats=None, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
-                               dbeta=self.p.grad(bn.name + '.bias'), bn=bn))
+                               dbeta=self.p.grad(bn.name + '.bias'), bn=bn, lane=self._home(x)))
             del self._bn_pending[key]
 
     def build_backward(self):
@@ -393,23 +467,35 @@ class HourglassGraph:
         # first backward op runs, so they must be placed here, not at their first use deep inside the backward list
         self.bwd.append(Op('seed', extra_in=list(self.outputs), extra_out=list(self.out_grads)))
         for op in reversed(self.fwd):
+            self._lane = op.lane                 # gradients flow on the lane of the forward op they belong to
+            if len(self._wg_pending) >= self.wgrad_batch and op.lane == 0:
+                self._flush_wgrads()
             if op.kind == 'conv':
                 self._conv_backward(op)
             elif op.kind == 'stem_fwd':
                 dy = op.y.grad
                 self.bwd.append(Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
-                                   dbias=self.p.grad('conv1.bias'), dims=op.dims))
+                                   dbias=self.p.grad('conv1.bias'), dims=op.dims, lane=1 + self.depth))
             elif op.kind == 'ew':
                 self._ew_backward(op)
+        self._lane = 0
+        self._flush_wgrads()
         assert not self._bn_pending, 'unfinished BN backward: %r' % list(self._bn_pending)
+
+    def _flush_wgrads(self):
+        """Weight gradients are leaves: they are collected and issued in batches on their own lane, newest first, so
+        that the batch's first kernel carries the one cross-lane wait that covers the whole batch."""
+        for w in reversed(self._wg_pending):
+            self.bwd.append(w)
+        self._wg_pending = []
 
     def _conv_backward(self, op):
         dy = op.y.grad
         if dy is None:
             return
         x = op.x
-        self.bwd.append(Op('wgrad', x=x, dy=dy, dw=self.p.grad(op.wkey), dbias=self.p.grad(op.bkey), bn=op.bn,
-                           dims=op.dims))
+        self._wg_pending.append(Op('wgrad', x=x, dy=dy, dw=self.p.grad(op.wkey), dbias=self.p.grad(op.bkey), bn=op.bn,
+                                   dims=op.dims, lane=1 + self.depth))
         if op.residual is not None:
             self._contribute_identity(op.residual, dy)
         if not x.needs_grad:
@@ -426,7 +512,8 @@ class HourglassGraph:
         else:
             add, out = self._contribute(x)
             self.bwd.append(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=out,
-                               out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims))
+                               out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims,
+                               lane=self._home(x) if add is not None else None))
 
     def _ew_backward(self, op):
         dy = op.y.grad

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libfpd_amd.so')
+LIB_PATH = os.environ.get('FPD_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libfpd_amd.so')
 
 F32, BF16 = 0, 1
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
@@ -112,6 +112,7 @@ SYMBOLS = {
     'fpd_plan_destroy': (None, [_vp]),
     'fpd_plan_add': (C.c_int, [_vp, _i32, _vp, _i64]),
     'fpd_plan_size': (C.c_int, [_vp]),
+    'fpd_plan_set_schedule': (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_int32), _i32]),
     'fpd_plan_run': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpd_plan_capture': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpd_plan_replay': (C.c_int, [_vp, _i32, _vp]),
@@ -191,6 +192,10 @@ class Plan:
 
     def __len__(self):
         return self._l.fpd_plan_size(self._p)
+
+    def set_schedule(self, op, lane, waits=()):
+        arr = (C.c_int32 * max(len(waits), 1))(*waits)
+        check(self._l.fpd_plan_set_schedule(self._p, op, lane, arr, len(waits)), 'fpd_plan_set_schedule')
 
     def run(self, begin, end, stream=None):
         check(self._l.fpd_plan_run(self._p, begin, end, stream if stream is not None else current_stream()),

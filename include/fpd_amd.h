@@ -228,7 +228,14 @@ void fpd_plan_destroy(fpd_plan* p);
 /* appends one op (args are copied); returns its index or <0 */
 int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t args_bytes);
 int fpd_plan_size(const fpd_plan* p);
-/* launch ops [begin,end) on stream */
+/* multi-lane schedule: op `op` is issued on lane `lane` (0 = the stream passed to run/capture, >0 = a stream owned
+ * by the plan) after the ops listed in wait_ops[0..n_waits) (indices of ops on OTHER lanes) have completed; ops of
+ * one lane execute in plan order.  Every fpd_plan_run/capture range forks the side lanes from `stream` at its start
+ * and joins them back into `stream` at its end, so waits never need to cross a range boundary (such entries are
+ * ignored).  Default for every op: lane 0, no waits = the plain in-order list. */
+#define FPD_MAX_LANES 16
+int fpd_plan_set_schedule(fpd_plan* p, int32_t op, int32_t lane, const int32_t* wait_ops, int32_t n_waits);
+/* launch ops [begin,end) on stream (and the plan's side-lane streams, see above) */
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
 /* capture ops [begin,end) into a hipGraph once, then replay it (graph id returned by capture) */
 int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);

@@ -129,3 +129,55 @@ def test_seeded_backward_without_loss_op():
     tr = _cases.truth64('tiny')
     t64 = torch.cat([tr['grads'][k].reshape(-1) for k in table.trainable_keys()]).numpy()
     _cases.assert_parity(flat.numpy(), gold['grad_flat'], t64, 'seeded gradients', floor=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize('delay', [0, 8])
+def test_multi_lane_schedule_is_sound(delay):
+    """Brute force: every pair of ops that touch overlapping physical memory, at least one of them writing, must be
+    ordered (lane order + event waits) the way the sequential list orders them -- including overlaps that only exist
+    because the memory planner reused a block or the IR accumulates a gradient in place."""
+    from fpd_amd.schedule import PhaseSchedule
+    c, table, g = build('tiny', train=True, wlp_is_master=False)
+    G.plan_memory(g.fwd + g.bwd, reuse_delay=delay)
+    assert g.n_lanes == 1 + g.depth + G.WGRAD_LANES
+    for phase in (list(g.fwd), [None] + [o for o in g.bwd if o.kind != 'seed'] + [None]):
+        entries = [((o.lane or 0), o.accesses()) if o is not None else (0, None) for o in phase]
+        sch = PhaseSchedule(entries, g.n_lanes)
+        assert len({l for l, _ in entries}) >= 3                      # the phase really is multi-lane
+        recs = []                                                      # (arena, start, end, op, write)
+        for i, (lane, acc) in enumerate(entries):
+            if acc is None:
+                for j in range(i):
+                    assert sch.happens_before(j, i), ('barrier', j, i)
+                for j in range(i + 1, len(entries)):
+                    assert sch.happens_before(i, j), ('after barrier', i, j)
+                continue
+            for bufs, wr in ((acc[0], False), (acc[1], True)):
+                for b in bufs:
+                    recs.append((b.arena, b.off, b.off + b.numel, i, wr))
+        checked = 0
+        for x, (a1, s1, e1, i1, w1) in enumerate(recs):
+            for (a2, s2, e2, i2, w2) in recs[x + 1:]:
+                if i1 != i2 and a1 == a2 and s1 < e2 and s2 < e1 and (w1 or w2):
+                    assert sch.happens_before(min(i1, i2), max(i1, i2)), (phase[i1].kind, i1, phase[i2].kind, i2, a1)
+                    checked += 1
+        assert checked > len(entries)
+        for i, ws in enumerate(sch.waits):                              # waits point backwards, to other lanes
+            assert all(w < i and sch.lanes[w] != sch.lanes[i] for w in ws)
+
+
+def test_lanes_follow_the_hourglass_structure():
+    c, table, g = build('tiny', train=True)
+    # hg.<s>.hg.<level>.0.*: up-branch of hourglass level <level>+1; only the LANE_LEVELS largest get a lane
+    up = [o for o in g.fwd if o.kind == 'conv' and '.hg.' in o.wkey and o.wkey.split('.')[4] == '0'
+          and int(o.wkey.split('.')[3]) + 1 > g.depth - G.LANE_LEVELS]
+    assert up and all(o.lane == int(o.wkey.split('.')[3]) + 1 for o in up)
+    assert all(o.lane == 0 for o in g.fwd if o not in up)
+    assert all(o.lane > g.depth for o in g.bwd if o.kind in ('wgrad', 'stem_wgrad'))
+    # weight gradients are deferred into batches: the gradient tensors they read must never be written twice
+    nwrites = {}
+    for o in g.bwd:
+        if o.kind in ('conv', 'ew'):
+            nwrites[id(o.y)] = nwrites.get(id(o.y), 0) + 1
+    wg = [o for o in g.bwd if o.kind == 'wgrad']
+    assert wg and all(nwrites.get(id(o.dy), 0) <= 1 for o in wg)
