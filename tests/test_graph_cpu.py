@@ -9,12 +9,12 @@ from oracle import hourglass_ref, plan_interp as PI
 from tests import _cases, _interp_util as U
 
 
-def build(name, train, which='s', wlp_is_master=True):
+def build(name, train, which='s', wlp_is_master=True, **kw):
     c = _cases.CONFIGS[name]
     feats, stacks = c[which]
     table = G.ParamTable(hourglass_ref.hourglass_keys(feats, stacks, c['joints']))
     g = G.HourglassGraph(table, feats, stacks, c['joints'], c['batch'], c['image'][1], c['image'][0], train,
-                         wlp_is_master=wlp_is_master)
+                         wlp_is_master=wlp_is_master, **kw)
     return c, table, g
 
 
@@ -131,19 +131,19 @@ def test_seeded_backward_without_loss_op():
     _cases.assert_parity(flat.numpy(), gold['grad_flat'], t64, 'seeded gradients', floor=2e-6, atol=1e-5)
 
 
-@pytest.mark.parametrize('delay', [0, 8])
-def test_multi_lane_schedule_is_sound(delay):
+@pytest.mark.parametrize('delay,levels', [(0, 2), (8, 4), (8, 0)])
+def test_multi_lane_schedule_is_sound(delay, levels):
     """Brute force: every pair of ops that touch overlapping physical memory, at least one of them writing, must be
     ordered (lane order + event waits) the way the sequential list orders them -- including overlaps that only exist
     because the memory planner reused a block or the IR accumulates a gradient in place."""
     from fpd_amd.schedule import PhaseSchedule
-    c, table, g = build('tiny', train=True, wlp_is_master=False)
+    c, table, g = build('tiny', train=True, wlp_is_master=False, lane_levels=levels, wgrad_batch=7)
     G.plan_memory(g.fwd + g.bwd, reuse_delay=delay)
     assert g.n_lanes == 1 + g.depth + G.WGRAD_LANES
     for phase in (list(g.fwd), [None] + [o for o in g.bwd if o.kind != 'seed'] + [None]):
         entries = [((o.lane or 0), o.accesses()) if o is not None else (0, None) for o in phase]
         sch = PhaseSchedule(entries, g.n_lanes)
-        assert len({l for l, _ in entries}) >= 3                      # the phase really is multi-lane
+        assert len({l for l, _ in entries}) >= 1 + levels            # the phase really is multi-lane
         recs = []                                                      # (arena, start, end, op, write)
         for i, (lane, acc) in enumerate(entries):
             if acc is None:
@@ -166,12 +166,13 @@ def test_multi_lane_schedule_is_sound(delay):
             assert all(w < i and sch.lanes[w] != sch.lanes[i] for w in ws)
 
 
-def test_lanes_follow_the_hourglass_structure():
-    c, table, g = build('tiny', train=True)
-    # hg.<s>.hg.<level>.0.*: up-branch of hourglass level <level>+1; only the LANE_LEVELS largest get a lane
+@pytest.mark.parametrize('levels', [0, 2])
+def test_lanes_follow_the_hourglass_structure(levels):
+    c, table, g = build('tiny', train=True, lane_levels=levels)
+    # hg.<s>.hg.<level>.0.*: up-branch of hourglass level <level>+1; only the `lane_levels` largest get a lane
     up = [o for o in g.fwd if o.kind == 'conv' and '.hg.' in o.wkey and o.wkey.split('.')[4] == '0'
-          and int(o.wkey.split('.')[3]) + 1 > g.depth - G.LANE_LEVELS]
-    assert up and all(o.lane == int(o.wkey.split('.')[3]) + 1 for o in up)
+          and int(o.wkey.split('.')[3]) + 1 > g.depth - levels]
+    assert (up or not levels) and all(o.lane == int(o.wkey.split('.')[3]) + 1 for o in up)
     assert all(o.lane == 0 for o in g.fwd if o not in up)
     assert all(o.lane > g.depth for o in g.bwd if o.kind in ('wgrad', 'stem_wgrad'))
     # weight gradients are deferred into batches: the gradient tensors they read must never be written twice
