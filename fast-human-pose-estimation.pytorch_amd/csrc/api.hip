@@ -11,6 +11,8 @@
 
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
+int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_partials(const fpd_wgrad_t& a);
@@ -69,7 +71,7 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t);
 #undef SZ
     return -1;
 }
@@ -89,6 +91,37 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
+    return rc ? rc : check_launch();
+}
+
+static int validate_bneck_bns(const fpd_bneck_t* a) {
+    const fpd_bn_t* bns[3] = {&a->bn1, &a->bn2, &a->bn3};
+    for (int i = 0; i < 3; ++i)
+        FPD_REQUIRE(bns[i]->mode == FPD_BN_EVAL && bns[i]->relu && bns[i]->gamma && bns[i]->beta && bns[i]->running_mean &&
+                    bns[i]->running_var, "bottleneck: bn%d must be an eval-mode BN+ReLU with running statistics", i + 1);
+    return 0;
+}
+
+int fpd_bottleneck_fold(const fpd_bneck_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->folded, "bottleneck_fold: null pointer");
+    int rc = validate_bneck_bns(a);
+    if (rc) return rc;
+    rc = fpd_bneck_fold_launch(*a, const_cast<float*>(a->folded), (hipStream_t)stream);
+    if (rc == 1) return fpd_fail(-3, "bottleneck_fold: C=%d P=%d is outside the fused kernel's domain", a->C, a->P);
+    return rc ? rc : check_launch();
+}
+
+int fpd_bottleneck_forward(const fpd_bneck_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->x && a->y && a->w1 && a->w2 && a->w3, "bottleneck: null pointer");
+    FPD_REQUIRE(a->x != a->y, "bottleneck: y must not alias x");
+    FPD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->P > 0, "bottleneck: bad dims");
+    FPD_REQUIRE((int64_t)a->N * a->H * a->W * a->C < ((int64_t)1 << 31), "bottleneck: tensor too large for 32-bit indexing");
+    int rc = validate_bneck_bns(a);
+    if (rc) return rc;
+    rc = fpd_bneck_fused_launch(*a, (hipStream_t)stream);
+    if (rc == 1)
+        return fpd_fail(-3, "bottleneck: shape N=%d H=%d W=%d C=%d P=%d dtype=%d is outside the fused kernel's domain",
+                        a->N, a->H, a->W, a->C, a->P, a->dtype);
     return rc ? rc : check_launch();
 }
 
@@ -178,7 +211,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_conv_t conv; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_conv_t conv; fpd_bneck_t bneck; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -222,6 +255,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
     switch (op) {
         case FPD_OP_CONV: want = sizeof(fpd_conv_t); break;
         case FPD_OP_WGRAD: want = sizeof(fpd_wgrad_t); break;
+        case FPD_OP_BNECK: case FPD_OP_BNECK_FOLD: want = sizeof(fpd_bneck_t); break;
         case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: want = sizeof(fpd_stem_t); break;
         case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
         case FPD_OP_LOSS: want = sizeof(fpd_loss_t); break;
@@ -254,6 +288,8 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
     switch (o.type) {
         case FPD_OP_CONV: return fpd_conv_forward(&o.u.conv, s);
         case FPD_OP_WGRAD: return fpd_conv_wgrad(&o.u.wgrad, s);
+        case FPD_OP_BNECK: return fpd_bottleneck_forward(&o.u.bneck, s);
+        case FPD_OP_BNECK_FOLD: return fpd_bottleneck_fold(&o.u.bneck, s);
         case FPD_OP_STEM_FWD: return fpd_stem_forward(&o.u.stem, s);
         case FPD_OP_STEM_WGRAD: return fpd_stem_wgrad(&o.u.stem, s);
         case FPD_OP_EW: return fpd_elementwise(&o.u.ew, s);

@@ -1,0 +1,481 @@
+// bneck_fused: one launch for a whole pre-activation Bottleneck of a FROZEN (eval-mode BN) hourglass:
+//     y = x + conv3( relu(bn3( conv2( relu(bn2( conv1( relu(bn1(x)) ) )) ) )) )        (hourglass.py:32-52)
+// with conv1 1x1 C->P, conv2 3x3 P->P (pad 1), conv3 1x1 P->C, C = 2P.  Eval-mode BN has no batch-wide dependency,
+// so both P-channel intermediates stay in LDS: versus three conv launches this removes two tensor round trips through
+// HBM (~45 % of the bytes at 64x64) and two of three launch latencies (all that matters at 4x4..16x16).
+//
+// One block = 128 consecutive output pixels (whole image rows, 128 % W == 0), 8 wave64, 1 block per CU.
+//   phase A  conv1 over the tile PLUS its one-row halo (<= 2 passes of 128 pixels; K = C in chunks of 64 staged
+//            through LDS with bn1+ReLU applied on the way in).  Result -> bn2+ReLU -> bf16 -> LDS image `a2`
+//            laid out like conv_tile's halo tile (rows of W+2 pixels, explicit zero border columns, one zero pixel
+//            that lanes whose tap row falls outside their image read instead).
+//   phase B  conv2: 9 taps x K = P from `a2`; weight tiles [P][P] double-buffered in LDS, next tile prefetched in
+//            registers.  Result -> bn3+ReLU -> bf16 -> LDS `a3` (aliases a2).
+//   phase C  conv3 = two more steps of the same pipeline (rows [0,P) and [P,2P) of w3 are [P][P] tiles), then the
+//            epilogue: fp32 staging per wave, + bias + residual x, one rounding, 128-byte row segments to HBM.
+// All MFMAs run "transposed" (first operand = weights, second = pixels): a lane then owns 4 CONSECUTIVE channels of
+// one pixel per register quad, so the LDS intermediates are written as packed 8-byte vectors.
+// Rounding: each intermediate is rounded to bf16 once (after bias+BN+ReLU); the 3-launch path rounds the raw conv
+// output and again after BN.  oracle/plan_interp.py `run_bneck` is the specification of this op.
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: typed loads/stores (a uint4 struct
+                                                                  // copy is a memcpy, which keeps its array in scratch)
+// compile-time loop: register arrays indexed through it are scalarised at the first SROA run (a `#pragma unroll`
+// loop is unrolled too late for the 512-thread register budget and the array ends up in scratch)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+#ifdef FPD_BNECK_TIMING          // probe build only (tools/bneck_bench.py): cycle stamps of block 0 at the phase boundaries
+#define STAMP(i) do { if (tid == 0 && blockIdx.x == 0) stamps[i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// Folded per-channel tables, [3C + 4P] floats: sc1[C] sh1[C] | sc2[P] sh2'[P] | sc3[P] sh3'[P] | b3[C] with
+// sh2' = sh2 + sc2*b1, sh3' = sh3 + sc3*b2 (conv biases folded into the following BN).
+template <int P>
+__device__ __forceinline__ void bneck_fold_tables(const fpd_bneck_t& a, float* out, int tid, int nthreads) {
+    constexpr int C = 2 * P;
+    for (int c = tid; c < C; c += nthreads) {
+        float sc, sh, mu, is;
+        bn_coef(a.bn1, c, C, 1.0, sc, sh, mu, is);
+        out[c] = sc;
+        out[C + c] = sh;
+        out[2 * C + 4 * P + c] = a.b3 ? a.b3[c] : 0.f;
+    }
+    for (int c = tid; c < 2 * P; c += nthreads) {
+        const bool second = c >= P;
+        const int cc = second ? c - P : c;
+        float sc, sh, mu, is;
+        bn_coef(second ? a.bn3 : a.bn2, cc, P, 1.0, sc, sh, mu, is);
+        const float* bias = second ? a.b2 : a.b1;
+        out[2 * C + (second ? 2 * P : 0) + cc] = sc;
+        out[2 * C + (second ? 2 * P : 0) + P + cc] = fmaf(sc, bias ? bias[cc] : 0.f, sh);
+    }
+}
+
+template <int P>
+__global__ void bneck_fold_kernel(const fpd_bneck_t a, float* out) { bneck_fold_tables<P>(a, out, threadIdx.x, blockDim.x); }
+
+template <int P>
+__global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int swz) {
+    constexpr int C = 2 * P;
+    constexpr int LDX = 64 + 8;                 // phase-A staging rows (bf16 elements)
+    constexpr int LD2 = P + 8;                  // a2 / a3 rows and [P][P] weight-tile rows
+    constexpr int TNH = P / 64;                 // 32-channel MFMA tiles per wave (a wave owns half of a P-wide tile)
+    constexpr int CW = 32 * TNH;                // channels per wave per step
+    constexpr int NSTEP = 9 + 2;
+    constexpr int VPR2 = P / 8;                 // 16-byte vectors per [.][P] row
+    constexpr int WV = P * VPR2 / 512;          // vectors per thread of a [P][P] tile
+    constexpr int W1V = P * 8 / 512;            // vectors per thread of a [P][64] w1 chunk
+    constexpr int NCH = C / 64;                 // channel chunks of conv1's reduction (even)
+    constexpr int ASTG = (128 + P) * LDX;       // one phase-A staging buffer: x chunk [128][LDX] + w1 chunk [P][LDX]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FPD_BNECK_TIMING
+    long long stamps[8];
+#endif
+    STAMP(0);
+    const int q = wave & 3, hC = wave >> 2;     // pixel group (32 px) and channel half of this wave
+    const int koff = 8 * (lane >> 5);
+    const int H = a.H, W = a.W;
+    const int M = a.N * H * W, GR = a.N * H;
+    const int nrows = 128 >> logW, hrows = nrows + 2, WP = W + 2;
+    const int zero_px = hrows * WP;
+    int bid = blockIdx.x;
+    if (swz) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // blocks of one XCD work on neighbouring tiles
+    const int m0 = bid * 128, g0 = m0 >> logW;
+
+    float* s_sc1 = reinterpret_cast<float*>(smem);
+    float* s_sh1 = s_sc1 + C;
+    float* s_sc2 = s_sh1 + C;
+    float* s_sh2 = s_sc2 + P;
+    float* s_sc3 = s_sh2 + P;
+    float* s_sh3 = s_sc3 + P;
+    float* s_b3 = s_sh3 + P;
+    bf16_t* sA2 = reinterpret_cast<bf16_t*>(s_b3 + C);
+    bf16_t* sR2 = sA2 + (zero_px + 3) * LD2;     // 3 zero pixels: the column tap offset is added to a redirected address too
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* __restrict__ w1 = reinterpret_cast<const bf16_t*>(a.w1);
+    const bf16_t* __restrict__ w2 = reinterpret_cast<const bf16_t*>(a.w2);
+    const bf16_t* __restrict__ w3 = reinterpret_cast<const bf16_t*>(a.w3);
+
+    // ---- phase-A addressing (hoisted: the pipeline steps below must not spend VALU cycles on address arithmetic) ----
+    // Tiles made of whole images never read their halo rows (every out-of-image tap is redirected to the zero pixels):
+    // one pass over the tile's own 128 pixels (halo-pixel index W..W+127) is enough.
+    const bool whole = (128 % (H * W)) == 0;
+    const int hp0 = whole ? W : 0;
+    const int npass = whole ? 1 : ((hrows * W + 127) >> 7);
+    const int xpx = tid >> 3, xcv = (tid & 7) * 8;       // this thread stages pixels xpx, xpx+64, channels xcv..+7
+    int xo[2];                                           // element offsets of the two pixels in the pass being loaded
+    bool xok[2];
+    auto pass_addr = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hp = hp0 + 128 * p + xpx + 64 * i;
+            const int hr = hp >> logW, j = hp & (W - 1);
+            const int g = g0 - 1 + hr;
+            xok[i] = hr < hrows && (unsigned)g < (unsigned)GR;
+            xo[i] = xok[i] ? (g * W + j) * C + xcv : 0;
+        }
+    };
+    int w1o[W1V], w1l[W1V];
+#pragma unroll
+    for (int i = 0; i < W1V; ++i) {
+        const int v = tid + i * 512;
+        w1o[i] = (v >> 3) * C + (v & 7) * 8;
+        w1l[i] = 128 * LDX + (v >> 3) * LDX + (v & 7) * 8;
+    }
+    const int xl = xpx * LDX + xcv;
+
+    u32x4 rx[NCH][2], rw[NCH][W1V];
+    auto a_load = [&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value;
+        static_for<2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rx[kc][i] = z;
+            if (xok[i]) rx[kc][i] = *reinterpret_cast<const u32x4*>(x + (xo[i] + kc * 64));
+        });
+        static_for<W1V>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            rw[kc][i] = *reinterpret_cast<const u32x4*>(w1 + (w1o[i] + kc * 64));
+        });
+    };
+    auto a_store = [&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value;
+        bf16_t* dst = sR2 + (kc & 1) * ASTG;
+        f32x4 sc[2], sh[2];
+        sc[0] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv);
+        sc[1] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv + 4);
+        sh[0] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv);
+        sh[1] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv + 4);
+        static_for<2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            float f[8];
+            const u32x4 r = rx[kc][i];
+            DT<bf16_t>::unpack(make_uint4(r[0], r[1], r[2], r[3]), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), 0.f);
+            *reinterpret_cast<uint4*>(dst + xl + 64 * i * LDX) = DT<bf16_t>::pack(f);
+        });
+        static_for<W1V>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            *reinterpret_cast<u32x4*>(dst + w1l[i]) = rw[kc][i];
+        });
+    };
+    // ---- weight-tile pipeline of phases B/C: two register sets, tile t travels in set t & 1 and is requested two
+    //      steps before the step that multiplies with it ----
+    int t2o[WV], t3o[WV], tlo[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int v = tid + i * 512;
+        const int row = v / VPR2, col = (v - row * VPR2) * 8;
+        t2o[i] = row * 9 * P + col;
+        t3o[i] = row * P + col;
+        tlo[i] = row * LD2 + col;
+    }
+    u32x4 rb[2][WV];
+    auto t_load = [&](auto sc_) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc_)::value;
+        static_for<WV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const bf16_t* src = s < 9 ? w2 + (t2o[i] + s * P) : w3 + (t3o[i] + (s - 9) * P * P);
+            rb[s & 1][i] = *reinterpret_cast<const u32x4*>(src);
+        });
+    };
+    auto t_store = [&](auto sc_) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc_)::value;
+        bf16_t* dst = sR2 + (s & 1) * P * LD2;
+        static_for<WV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            *reinterpret_cast<u32x4*>(dst + tlo[i]) = rb[s & 1][i];
+        });
+    };
+
+    // first loads go out before anything else: everything below (tables, zero fill) hides under their latency
+    pass_addr(0);
+    static_for<NCH>([&](auto kcc) { a_load(kcc); });
+    if (npass > 1) pass_addr(1);
+
+    // ---- tables: folded by the host-side prep pass (a.folded) or here ----
+    if (a.folded != nullptr) {
+        for (int v = tid; v < (3 * C + 4 * P) / 4; v += 512)
+            reinterpret_cast<f32x4*>(s_sc1)[v] = reinterpret_cast<const f32x4*>(a.folded)[v];
+    } else {
+        bneck_fold_tables<P>(a, s_sc1, tid, 512);
+    }
+    // zero border columns of every halo row + the zero pixels (whole LD2 rows, 16-byte vectors)
+    {
+        constexpr int VR = LD2 / 8;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int v = tid; v < (2 * hrows + 3) * VR; v += 512) {
+            const int pz = v / VR, cv = (v - pz * VR) * 8;
+            const int px = pz < 2 * hrows ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - 2 * hrows);
+            *reinterpret_cast<uint4*>(sA2 + px * LD2 + cv) = z;
+        }
+    }
+    __syncthreads();                             // tables visible to a_store
+    STAMP(1);
+
+    // =========================== phase A: conv1 over the halo rows ===========================
+    // All NCH channel chunks of a pass are in flight in registers; the slot a chunk frees is refilled with the same
+    // chunk of the NEXT pass (in the last pass: with the first weight tiles of phase B).  Staging is double-buffered:
+    // chunk k+1 gets its bn1+ReLU and goes to LDS while the MFMAs of chunk k run; one barrier per chunk.
+    auto refill = [&](auto kcc, int pp) __attribute__((always_inline)) {      // slot kcc held pass pp, now stored
+        constexpr int kc = decltype(kcc)::value;
+        if (pp + 1 < npass) a_load(kcc);                                       // xo/xok already describe pass pp+1
+        else if constexpr (kc < 2) t_load(kcc);
+    };
+    a_store(std::integral_constant<int, 0>{});
+    refill(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    for (int p = 0; p < npass; ++p) {
+        f32x16 acc[TNH];
+#pragma unroll
+        for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
+        static_for<NCH>([&](auto kcc) {
+            constexpr int kc = decltype(kcc)::value;
+            if constexpr (kc + 1 < NCH) {
+                a_store(std::integral_constant<int, (kc + 1) % NCH>{});
+                refill(std::integral_constant<int, (kc + 1) % NCH>{}, p);
+            } else {
+                if (p + 1 < npass) {
+                    a_store(std::integral_constant<int, 0>{});
+                    if (p + 2 < npass) pass_addr(p + 2);                       // (never taken: npass <= 2)
+                    refill(std::integral_constant<int, 0>{}, p + 1);
+                }
+            }
+            const bf16_t* xrow = sR2 + (kc & 1) * ASTG + (q * 32 + (lane & 31)) * LDX + koff;
+            const bf16_t* wrow = sR2 + (kc & 1) * ASTG + 128 * LDX + (hC * CW + (lane & 31)) * LDX + koff;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 px = *reinterpret_cast<const bf16x8*>(xrow + kk * 16);
+#pragma unroll
+                for (int tn = 0; tn < TNH; ++tn) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + tn * 32 * LDX + kk * 16);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, px, acc[tn], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        });
+        // a2 = relu(bn2(conv1 + b1)) as bf16; rows of the zero-column layout.  Halo pixels outside the tensor hold
+        // junk that no lane reads (their readers are redirected to the zero pixels).
+        const int hp = hp0 + 128 * p + q * 32 + (lane & 31);
+        const int hr = hp >> logW, j = hp & (W - 1);
+        if (hr < hrows) {
+            bf16_t* dst = sA2 + (hr * WP + j + 1) * LD2;
+#pragma unroll
+            for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int c = hC * CW + tn * 32 + 8 * gi + 4 * (lane >> 5);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc2 + c);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(s_sh2 + c);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[tn][4 * gi + e], sc[e], sh[e]), 0.f);
+                    *reinterpret_cast<uint2*>(dst + c) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+                }
+        }
+    }
+
+    // =========================== phases B + C: 11-step weight-tile pipeline ===========================
+    const int ml = q * 32 + (lane & 31);
+    int ab[3];
+    {
+        const int ti = ml >> logW, tj = ml & (W - 1);
+        const int g = g0 + ti;
+        const int pr = g % H;
+        const bool live = g < GR;
+        ab[0] = (live && pr - 1 >= 0) ? ((ti + 0) * WP + tj) * LD2 : zero_px * LD2;
+        ab[1] = live ? ((ti + 1) * WP + tj) * LD2 : zero_px * LD2;
+        ab[2] = (live && pr + 1 < H) ? ((ti + 2) * WP + tj) * LD2 : zero_px * LD2;
+    }
+    STAMP(2);
+    // (the last barrier of phase A already separates its staging reads from the tile stores below)
+    t_store(std::integral_constant<int, 0>{});
+    t_load(std::integral_constant<int, 2>{});
+    __syncthreads();                             // tile 0 + the whole a2 image visible
+    STAMP(3);
+
+    f32x16 accB[TNH], accC[2][TNH];
+#pragma unroll
+    for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accB[tn][i] = 0.f;
+
+    auto mma = [&](const bf16_t* arow, int buf, f32x16* acc) __attribute__((always_inline)) {
+        const bf16_t* wrow = sR2 + buf * P * LD2 + (hC * CW + (lane & 31)) * LD2 + koff;
+#pragma unroll
+        for (int kk = 0; kk < P / 16; ++kk) {
+            const bf16x8 px = *reinterpret_cast<const bf16x8*>(arow + kk * 16);
+#pragma unroll
+            for (int tn = 0; tn < TNH; ++tn) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + tn * 32 * LD2 + kk * 16);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, px, acc[tn], 0, 0, 0);
+            }
+        }
+    };
+
+    // residual rows of the epilogue, requested under the last pipeline steps
+    constexpr int VW = CW / 8;                   // output vectors per pixel row of this wave's channel slice
+    constexpr int NIT = 32 * VW / 64;
+    u32x4 rres[2][NIT];
+    auto res_load = [&](auto stc) __attribute__((always_inline)) {
+        constexpr int st = decltype(stc)::value;
+        static_for<NIT>([&](auto itc) {
+            constexpr int it = decltype(itc)::value;
+            const int idx = lane + 64 * it;
+            const int px = idx / VW, cv = (idx - px * VW) * 8;
+            const int m = m0 + q * 32 + px;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rres[st][it] = z;
+            if (m < M) rres[st][it] = *reinterpret_cast<const u32x4*>(x + ((size_t)m * C + st * P + hC * CW + cv));
+        });
+    };
+
+    static_for<NSTEP>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if constexpr (s < 9) {
+            mma(sA2 + ab[s / 3] + (s % 3) * LD2 + koff, s & 1, accB);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accC[s - 9][tn][i] = 0.f;
+            mma(sA2 + ml * LD2 + koff, s & 1, accC[s - 9]);          // a3 aliases a2: [128 px][LD2]
+        }
+        if constexpr (s + 1 < NSTEP) {
+            t_store(std::integral_constant<int, s + 1>{});
+            if constexpr (s + 3 < NSTEP) t_load(std::integral_constant<int, (s + 3 < NSTEP ? s + 3 : 0)>{});
+            if constexpr (s == 8) res_load(std::integral_constant<int, 0>{});
+            if constexpr (s == 9) res_load(std::integral_constant<int, 1>{});
+            __syncthreads();
+        }
+        if constexpr (s == 8) {
+            STAMP(4);
+            // every wave is past its last a2 read: a3 = relu(bn3(conv2 + b2)) overwrites the image
+            bf16_t* dst = sA2 + ml * LD2;
+#pragma unroll
+            for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int c = hC * CW + tn * 32 + 8 * gi + 4 * (lane >> 5);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc3 + c);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(s_sh3 + c);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(accB[tn][4 * gi + e], sc[e], sh[e]), 0.f);
+                    *reinterpret_cast<uint2*>(dst + c) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+                }
+            __syncthreads();
+        }
+    });
+
+    STAMP(5);
+    // =========================== epilogue: y = conv3 + b3 + x ===========================
+    constexpr int LDS_ = CW + 4;
+    float* stage = reinterpret_cast<float*>(sR2) + wave * 32 * LDS_;       // wave-private [32 px][CW + 4] fp32
+    bf16_t* __restrict__ y = reinterpret_cast<bf16_t*>(a.y);
+    static_for<2>([&](auto stc) {
+        constexpr int st = decltype(stc)::value;
+        __syncthreads();                         // weight tiles consumed / previous staging read back
+#pragma unroll
+        for (int tn = 0; tn < TNH; ++tn)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = accC[st][tn][4 * gi + e];
+                *reinterpret_cast<f32x4*>(stage + (lane & 31) * LDS_ + tn * 32 + 8 * gi + 4 * (lane >> 5)) = v;
+            }
+        __syncthreads();
+        static_for<NIT>([&](auto itc) {
+            constexpr int it = decltype(itc)::value;
+            const int idx = lane + 64 * it;
+            const int px = idx / VW, cv = (idx - px * VW) * 8;
+            const int m = m0 + q * 32 + px;
+            if (m < M) {
+                const int c = st * P + hC * CW + cv;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + cv);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + cv + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b3 + c);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_b3 + c + 4);
+                float res[8], o[8];
+                const u32x4 r = rres[st][it];
+                DT<bf16_t>::unpack(make_uint4(r[0], r[1], r[2], r[3]), res);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = v0[e] + b0[e] + res[e];
+                    o[4 + e] = v1[e] + b1[e] + res[4 + e];
+                }
+                *reinterpret_cast<uint4*>(y + ((size_t)m * C + c)) = DT<bf16_t>::pack(o);
+            }
+        });
+    });
+#ifdef FPD_BNECK_TIMING
+    STAMP(6);
+    if (tid == 0 && blockIdx.x == 0)
+        printf("bneck W=%d: setup %lld | phaseA %lld | tile0 %lld | B(9 taps) %lld | a3+C %lld | epilogue %lld | total %lld cycles\n",
+               W, stamps[1] - stamps[0], stamps[2] - stamps[1], stamps[3] - stamps[2], stamps[4] - stamps[3],
+               stamps[5] - stamps[4], stamps[6] - stamps[5], stamps[6] - stamps[0]);
+#endif
+}
+
+template <int P>
+int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
+    constexpr int C = 2 * P, LD2 = P + 8, LDX = 72, CW = 32 * (P / 64);
+    const int hrows = (128 >> logW) + 2, WP = a.W + 2;
+    const size_t r2 = std::max({(size_t)2 * P * LD2 * 2, (size_t)2 * (128 + P) * LDX * 2, (size_t)8 * 32 * (CW + 4) * 4});
+    const size_t lds = (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_kernel<P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        configured = lds;
+    }
+    const int nblk = cdiv(a.N * a.H * a.W, 128);
+    hipLaunchKernelGGL((bneck_eval_kernel<P>), dim3(nblk), dim3(512), lds, st, a, logW, (nblk % 8 == 0) ? 1 : 0);
+    return 0;
+}
+
+}  // namespace
+
+static bool bneck_in_domain(const fpd_bneck_t& a) {
+    if (a.dtype != FPD_BF16 || a.C != 2 * a.P || (a.P != 64 && a.P != 128)) return false;
+    if (a.W < 4 || a.W > 64 || (a.W & (a.W - 1)) != 0) return false;
+    const int hw = a.H * a.W;
+    return hw % 128 == 0 || 128 % hw == 0;                    // a tile is whole rows of one image, or whole images
+}
+
+// 0 = launched, 1 = shape outside this kernel's domain, <0 = error
+int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st) {
+    if (!bneck_in_domain(a)) return 1;
+    int logW = 0;
+    while ((1 << logW) < a.W) ++logW;
+    return a.P == 128 ? launch_bneck<128>(a, logW, st) : launch_bneck<64>(a, logW, st);
+}
+
+// folded tables ([3C + 4P] floats) for a.folded; 1 = P not supported
+int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st) {
+    if (a.C != 2 * a.P || (a.P != 64 && a.P != 128)) return 1;
+    if (a.P == 128) hipLaunchKernelGGL((bneck_fold_kernel<128>), dim3(1), dim3(256), 0, st, a, out);
+    else hipLaunchKernelGGL((bneck_fold_kernel<64>), dim3(1), dim3(256), 0, st, a, out);
+    return 0;
+}

@@ -18,7 +18,7 @@ _EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd
        'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD}
 _ARENA_DTYPE = {'param': torch.float32, 'grad': torch.float32, 'rstat': torch.float32, 'nbt': torch.int64,
                 'stats': torch.float64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
-                'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32}
+                'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32, 'fold': torch.float32}
 
 
 def act_torch_dtype(dtype):
@@ -91,6 +91,17 @@ class Lowering:
         s.bn = self.bn(op.bn)
         s.epi_x, s.epi_bn, s.epi_stats = p(_abuf(op.epi_x)), self.bn(op.epi_bn), p(op.epi_stats)
         return R.OP_CONV, s
+
+    def bneck(self, op):
+        s = R.BneckT()
+        (s.N, s.H, s.W, s.C, s.P) = op.dims
+        s.dtype = self.dtype
+        p = self.A.ptr
+        s.x, s.y = p(_abuf(op.x)), p(_abuf(op.y))
+        s.w1, s.b1, s.w2, s.b2, s.w3, s.b3 = p(op.w1), p(op.b1), p(op.w2), p(op.b2), p(op.w3), p(op.b3)
+        s.bn1, s.bn2, s.bn3 = self.bn(op.bn1), self.bn(op.bn2), self.bn(op.bn3)
+        s.folded = p(getattr(op, 'folded', None))
+        return R.OP_BNECK, s
 
     def wgrad(self, op):
         s = R.WgradT()
@@ -192,7 +203,9 @@ class Lowering:
         return R.OP_MEMSET, s
 
     def op(self, op):
-        return {'conv': self.conv, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
+        if op.kind == 'bneck_fold':
+            return R.OP_BNECK_FOLD, self.bneck(op.target)[1]
+        return {'conv': self.conv, 'bneck': self.bneck, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
                 'bnupd': self.bnupd}[op.kind](op)
 
 
@@ -221,6 +234,7 @@ class GraphInstance:
         env = os.environ.get
         self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
                                   num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
+                                  fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
                                   lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
                                   wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
@@ -256,6 +270,7 @@ class GraphInstance:
         self.act_elems = act
         self.A.alloc('act', act)
         self.A.alloc('stats', g.stats_size)
+        self.A.alloc('fold', g.fold_size)
         if self._wlp_owner is not None:            # same ParamTable -> same layout of the working-weight arena
             assert self._wlp_owner.g.wlp_size == g.wlp_size and not self.train
             self.A.t['wlp'] = self._wlp_owner.A.t['wlp']
@@ -277,6 +292,9 @@ class GraphInstance:
                 entries.append((self.state.table[k], wf, wb))
         if entries:
             p.add(*self.low.wprep(entries))
+        for op in g.fwd:                           # frozen fused Bottlenecks: fold BN + biases into tables once
+            if op.kind == 'bneck' and getattr(op, 'folded', None) is not None:
+                p.add(*self.low.op(G.Op('bneck_fold', target=op)))
         self.rng['prep'] = (b, len(p))
         b = len(p)
         for op in g.fwd:

@@ -94,6 +94,10 @@ class Op:
         if k == 'conv':
             rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
             wr = [b(self.y), self.out_stats, self.epi_stats]
+        elif k == 'bneck':
+            rd = [b(self.x), self.w1, self.b1, self.w2, self.b2, self.w3, self.b3] + bn_bufs(self.bn1) + \
+                bn_bufs(self.bn2) + bn_bufs(self.bn3)
+            wr = [b(self.y)]
         elif k == 'wgrad':
             rd = [b(self.x), b(self.dy)] + bn_bufs(self.bn)
             wr = [self.dw, self.dbias]
@@ -247,13 +251,15 @@ class HourglassGraph:
     """Op lists for one (model, batch shape, train|eval) instance."""
 
     def __init__(self, params, num_feats, num_stacks, num_joints, batch, height, width, train, num_blocks=1,
-                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None):
+                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None, fuse_bneck=False):
         self.p = params
         self.F, self.S, self.J = num_feats, num_stacks, num_joints
         self.N, self.H, self.W = batch, height, width
         self.train, self.num_blocks, self.depth = train, num_blocks, depth
         self.wlp_is_master = wlp_is_master     # fp32 build: forward convs read the master weights directly
+        self.fuse_bneck = fuse_bneck and not train   # frozen bf16 networks: whole Bottleneck in one launch
         self.stats_size = 0
+        self.fold_size = 0                     # folded BN tables of fused Bottlenecks ('fold' arena, fp32)
         self.wlp_size = 0
         self.wfwd, self.wbwd = {}, {}
         self._lane = 0                         # lane 0 = the caller's stream; 1..depth = hourglass up-branches
@@ -349,12 +355,32 @@ class HourglassGraph:
         """hourglass.py:32-52 with bn_k+relu folded into conv_k's operand load."""
         c_in = x.shape[3]
         planes = self.p[p + 'conv1.weight'].shape[0]
+        if self.fuse_bneck and self.bneck_fusable(x.shape, planes) and (p + 'downsample.0.weight') not in self.p.entries:
+            n, h, w, _ = x.shape
+            y = Act(x.shape, p + 'out')
+            wb = (lambda k: self.p[k]) if self.wlp_is_master else (lambda k: self.wfwd[k])
+            fold = Buf('fold', self.fold_size, (3 * c_in + 4 * planes,), 'fold:' + p)
+            self.fold_size += 3 * c_in + 4 * planes
+            op = Op('bneck', x=x, y=y, dims=(n, h, w, c_in, planes), folded=fold,
+                    w1=wb(p + 'conv1.weight'), b1=self.p[p + 'conv1.bias'], w2=wb(p + 'conv2.weight'),
+                    b2=self.p[p + 'conv2.bias'], w3=wb(p + 'conv3.weight'), b3=self.p[p + 'conv3.bias'],
+                    bn1=self._bn(p + 'bn1', c_in), bn2=self._bn(p + 'bn2', planes), bn3=self._bn(p + 'bn3', planes))
+            y.producer = op
+            self.fwd.append(op)
+            return y
         t = self.conv(x, p + 'conv1', bn=self._bn(p + 'bn1', c_in))
         t = self.conv(t, p + 'conv2', bn=self._bn(p + 'bn2', planes), pad=1)
         skip = x
         if (p + 'downsample.0.weight') in self.p.entries:
             skip = self.conv(x, p + 'downsample.0')
         return self.conv(t, p + 'conv3', bn=self._bn(p + 'bn3', planes), residual=skip)
+
+    @staticmethod
+    def bneck_fusable(shape, planes):
+        """Domain of the fused kernel (csrc/bneck_fused.hip, fpd_bneck_t)."""
+        n, h, w, c = shape
+        return (c == 2 * planes and planes in (64, 128) and 4 <= w <= 64 and w & (w - 1) == 0 and
+                ((h * w) % 128 == 0 or 128 % (h * w) == 0))
 
     def residual_seq(self, x, p, nb):
         for b in range(nb):

@@ -80,6 +80,29 @@ typedef struct {
     double* epi_stats;     /* BNRELU_BWD: [R][2][K] += {sum dz, sum dz*xhat} */
 } fpd_conv_t;
 
+/* A whole pre-activation Bottleneck of a FROZEN network in one launch (hourglass.py:32-52 with eval-mode BN, no
+ * downsample branch):  y = x + conv3(relu(bn3(conv2(relu(bn2(conv1(relu(bn1(x)))))))))  with conv1 1x1 C->P,
+ * conv2 3x3 P->P pad 1, conv3 1x1 P->C.  Both P-channel intermediates stay in LDS (rounded to bf16 once, after
+ * bias+BN+ReLU).  Domain: dtype BF16, C == 2P, P in {64,128}, W a power of two in [4,64], H*W a multiple or a divisor
+ * of 128, every BN in EVAL mode; fpd_bottleneck_forward() returns an error outside it (callers then issue the three
+ * fpd_conv_forward() calls). */
+typedef struct {
+    int32_t N, H, W, C, P, dtype;
+    int32_t _pad[2];
+    const void* x;         /* [N,H,W,C] */
+    void* y;               /* [N,H,W,C] (must not alias x: neighbouring tiles re-read x rows) */
+    const void* w1;        /* [P][1][1][C] working-precision weights */
+    const float* b1;       /* [P] or NULL */
+    const void* w2;        /* [P][3][3][P] */
+    const float* b2;
+    const void* w3;        /* [C][1][1][P] */
+    const float* b3;       /* [C] or NULL */
+    fpd_bn_t bn1, bn2, bn3;
+    /* optional [3C + 4P] floats written by fpd_bottleneck_fold(): the three BNs folded to scale/shift with the conv1/conv2
+     * biases folded into the following shift, + b3.  A frozen model folds once; NULL = every block folds for itself. */
+    const float* folded;
+} fpd_bneck_t;
+
 /* Weight + bias gradient of the same conv (autograd of hourglass.py convs): dw[K][R][S][C] +=
  * sum_pixels dy * a(x), dbias[K] += sum_pixels dy.  fp32 atomics; caller zeroes dw/dbias. */
 typedef struct {
@@ -196,6 +219,10 @@ typedef struct {
 
 /* ---- single-op entry points (asynchronous on `stream`) ---- */
 int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream);
+/* fused frozen Bottleneck (three convs + three eval-mode BN+ReLU + residual), see fpd_bneck_t */
+int fpd_bottleneck_forward(const fpd_bneck_t* a, fpd_stream_t stream);
+/* writes a->folded (must be non-NULL) from a's BN / bias pointers; rerun whenever those parameters change */
+int fpd_bottleneck_fold(const fpd_bneck_t* a, fpd_stream_t stream);
 int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
 int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writes when a->partial is set */
 int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, int64_t max_elems, fpd_stream_t stream);
@@ -217,7 +244,8 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 /* ---- execution plan: a recorded list of the ops above, replayed with one call ---- */
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
-    FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10
+    FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
+    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

@@ -102,6 +102,28 @@ def run_conv(A, op):
     _store(A, op.y, y)
 
 
+def run_bneck(A, op):
+    """Fused frozen Bottleneck (include/fpd_amd.h fpd_bneck_t; /root/reference/lib/models/hourglass.py:32-52 in eval
+    mode).  Each intermediate is rounded to the storage precision ONCE, after bias + BN + ReLU."""
+    def conv(v, wbuf, pad):
+        wt = A.view(wbuf).float().permute(0, 3, 1, 2)
+        return F.conv2d(v.permute(0, 3, 1, 2), wt, None, stride=1, padding=pad).permute(0, 2, 3, 1)
+
+    def bn_act(v, bn, bias):
+        scale, shift, _, _ = _bn_coef(A, bn)
+        if bias is not None:
+            shift = torch.addcmul(shift, scale, A.view(bias))      # kernel folds the conv bias into the BN shift
+        return _rnd(A, torch.addcmul(shift, v, scale).clamp_min(0))
+    x = _act(A, op.x)
+    a1 = bn_act(x, op.bn1, None)
+    a2 = bn_act(conv(a1, op.w1, 0), op.bn2, op.b1)
+    a3 = bn_act(conv(a2, op.w2, 1), op.bn3, op.b2)
+    y = conv(a3, op.w3, 0) + x
+    if op.b3 is not None:
+        y = y + A.view(op.b3)
+    _store(A, op.y, y)
+
+
 def run_wgrad(A, op):
     n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
     x = _prologue(A, _act(A, op.x), op.bn).permute(0, 3, 1, 2)
@@ -237,7 +259,8 @@ def run_wprep(A, op):
 
 
 RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgrad': run_stem_wgrad, 'ew': run_ew,
-       'bnupd': run_bnupd, 'loss': run_loss, 'wprep': run_wprep}
+       'bnupd': run_bnupd, 'loss': run_loss, 'wprep': run_wprep, 'bneck': run_bneck,
+       'bneck_fold': lambda A, op: None}       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):

@@ -182,3 +182,33 @@ def test_lanes_follow_the_hourglass_structure(levels):
             nwrites[id(o.y)] = nwrites.get(id(o.y), 0) + 1
     wg = [o for o in g.bwd if o.kind == 'wgrad']
     assert wg and all(nwrites.get(id(o.dy), 0) <= 1 for o in wg)
+
+
+def test_fused_bottleneck_graph_matches_unfused():
+    """A frozen network built with fuse_bneck=True (one 'bneck' op per Bottleneck) computes what the three-conv graph
+    computes: in fp32 the two differ only by the conv-bias-into-BN-shift folding (rounding noise)."""
+    from oracle import fpd_ref
+    F_, S_, J = 128, 1, 4
+    keys = hourglass_ref.hourglass_keys(F_, S_, J)
+    sd = fpd_ref.synth_state_dict(keys, 7)
+    x, _, _ = fpd_ref.synth_batch(5, 1, J, image_size=(64, 64), heatmap_size=(16, 16))
+    outs = []
+    for fuse in (False, True):
+        table = G.ParamTable(keys)
+        g = G.HourglassGraph(table, F_, S_, J, 1, 64, 64, train=False, fuse_bneck=fuse)
+        kinds = {o.kind for o in g.fwd}
+        assert ('bneck' in kinds) == fuse
+        act = G.plan_memory(g.fwd)
+        A = U.make_arenas(g, table, act)
+        U.load_params(A, table, sd)
+        A.t['image'].copy_(x.reshape(-1))
+        PI.run(A, g.fwd)
+        outs.append(A.view(g.outputs[-1].buf).clone())
+    fused_ops = [o for o in G.HourglassGraph(G.ParamTable(keys), F_, S_, J, 1, 64, 64, train=False, fuse_bneck=True).fwd
+                 if o.kind == 'bneck']
+    assert len(fused_ops) == 9 and {o.dims[2] for o in fused_ops} == {16, 8, 4}      # 2x2 is outside the kernel's domain
+    err = float((outs[0] - outs[1]).abs().max())
+    assert err < 1e-4 * max(1.0, float(outs[0].abs().max())), err
+    # training graphs never fuse (train-mode BN needs batch statistics between the convs)
+    gt = G.HourglassGraph(G.ParamTable(keys), F_, S_, J, 1, 64, 64, train=True, fuse_bneck=True)
+    assert all(o.kind != 'bneck' for o in gt.fwd)

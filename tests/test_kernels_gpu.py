@@ -431,3 +431,59 @@ def test_error_paths_fail_loudly():
     a = R.ConvT()
     rc = R.lib().fpd_conv_forward(a, R.current_stream())
     assert rc != 0 and b'null' in R.lib().fpd_last_error()
+
+
+# ---- fused frozen Bottleneck (fpd_bottleneck_forward) -------------------------------------------------------------
+BNECK_CASES = [
+    # N, H, W, P   (C = 2P)
+    (2, 64, 64, 128),      # teacher level 64^2: two halo passes, tiles of two image rows
+    (3, 32, 32, 128),
+    (2, 16, 16, 128),      # image = two tiles
+    (4, 8, 8, 128),        # tile = two whole images
+    (5, 4, 4, 128),        # 80 pixels: one ragged tile of five whole images
+    (33, 4, 4, 128),       # several tiles, last one ragged
+    (2, 16, 16, 64),       # student widths
+    (1, 64, 64, 64),
+]
+
+
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('case', BNECK_CASES)
+def test_bottleneck_fused(case, fold):
+    """Fused kernel vs its CPU specification (oracle/plan_interp.run_bneck): bf16 storage, intermediates rounded once;
+    tolerance = bf16 output rounding (2^-8 relative) plus the occasional intermediate that rounds the other way."""
+    N, H, W, P = case
+    C = 2 * P
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    b = Bench(1)
+    x = b.act((N, H, W, C), rnd(gen, N, H, W, C))
+    y = b.act((N, H, W, C), torch.zeros(N, H, W, C))
+    w1 = b.buf('wlp', (P, 1, 1, C), rnd(gen, P, 1, 1, C, scale=(2.0 / C) ** 0.5))
+    w2 = b.buf('wlp', (P, 3, 3, P), rnd(gen, P, 3, 3, P, scale=(2.0 / (9 * P)) ** 0.5))
+    w3 = b.buf('wlp', (C, 1, 1, P), rnd(gen, C, 1, 1, P, scale=(2.0 / P) ** 0.5))
+    b1, b2, b3 = (b.buf('param', (n,), 0.1 * rnd(gen, n)) for n in (P, P, C))
+    bn1, bn2, bn3 = make_bn(b, gen, C, 'eval', 'bn1'), make_bn(b, gen, P, 'eval', 'bn2'), make_bn(b, gen, P, 'eval', 'bn3')
+    op = G.Op('bneck', x=x, y=y, dims=(N, H, W, C, P), w1=w1, b1=b1, w2=w2, b2=b2, w3=w3, b3=b3, bn1=bn1, bn2=bn2, bn3=bn3)
+    ops = [op]
+    if fold:                  # tables folded once by fpd_bottleneck_fold() instead of by every block
+        op.folded = b.buf('fold', (3 * C + 4 * P,), torch.full((3 * C + 4 * P,), float('nan')))
+        ops = [G.Op('bneck_fold', target=op), op]
+    b.realise()
+    b.run(ops, 0)
+    b.compare(y, 3e-2, 2e-2, 'bneck %r' % (case,))
+    ref = b.gpu.view(y.buf).float().cpu()
+    spec = b.cpu.view(y.buf).float()
+    rel = float((ref - spec).norm() / spec.norm())
+    assert rel < 3e-3, 'bneck %r: relative L2 vs specification %.3e' % (case, rel)
+
+
+def test_bottleneck_rejects_unsupported():
+    """Outside its domain the entry point fails loudly (callers issue the three conv launches instead)."""
+    a = R.BneckT()
+    a.N, a.H, a.W, a.C, a.P, a.dtype = 1, 8, 8, 256, 128, 0      # fp32 build is not supported
+    t = torch.zeros(8 * 8 * 256, device='cuda')
+    for f in ('x', 'w1', 'w2', 'w3'):
+        setattr(a, f, t.data_ptr())
+    a.y = torch.zeros(8 * 8 * 256, device='cuda').data_ptr()
+    rc = R.lib().fpd_bottleneck_forward(a, None)
+    assert rc != 0 and b'bn1' in R.lib().fpd_last_error()        # BN descriptors missing
