@@ -6,8 +6,10 @@ on synthetic 256x256 crops, batch 32 per GPU.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line on rank 0.  `roofline` prices one whole step (the unit the plan replays) against the dense
-bf16 MFMA peak with the algorithmic conv FLOPs of SURVEY.md section 8(d) (79.478 GFLOP per image);
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant single-shape kernel of the step -- the fused frozen
+Bottleneck of the teacher at 64x64 (17 launches/step, the largest single (kernel, shape) entry of the rocprof trace) --
+with its algorithmic conv FLOPs against the dense bf16 MFMA peak, timed live with HIP events on the launch stream;
+`roofline.step` prices one whole step (79.478 GFLOP per image) the same way.
 `cpu_baseline` times the CPU oracle (restatement of the reference loop, teacher under no_grad) on a bounded sample.
 """
 import argparse
@@ -47,6 +49,32 @@ def cpu_baseline(batch, steps, seed=0):
         fpd_ref.fpd_step(s_sd, t_sd, 4, 8, x, tg, tw, 0.5, adam_state=adam)
     dt = (time.time() - t0) / steps
     return batch / dt, dt
+
+
+def dominant_kernel(step, R, launches=50):
+    """Live timing of the dominant (kernel, shape): the teacher's first 64x64 fused Bottleneck, re-launched `launches`
+    times back to back on the current stream between two HIP events.  Returns None if the teacher graph is unfused."""
+    t = step.teacher
+    ops = [o for o in t.g.fwd if o.kind == 'bneck' and o.dims[1] == 64]
+    if not ops:
+        return None
+    op = ops[0]
+    n, h, w, c, p = op.dims
+    plan = R.Plan()
+    plan.add(*t.low.op(op))
+    l = R.lib()
+    st = R.current_stream()
+    for _ in range(3):
+        plan.run(0, 1)
+    e0, e1 = l.fpd_event_create(), l.fpd_event_create()
+    l.fpd_event_record(e0, st)
+    for _ in range(launches):
+        plan.run(0, 1)
+    l.fpd_event_record(e1, st)
+    us = l.fpd_event_elapsed_ms(e0, e1) / launches * 1e3
+    flops = 2.0 * n * h * w * (c * p + 9 * p * p + p * c)
+    return {'name': 'bneck_eval_kernel<128> N=%d %dx%d C=%d P=%d (teacher Bottleneck, conv1x1+conv3x3+conv1x1 fused)' % (n, h, w, c, p),
+            'us': us, 'flops': flops, 'bytes_algorithmic': 2.0 * n * h * w * c * 2, 'launches': launches}
 
 
 def main():
@@ -137,6 +165,28 @@ def main():
     flop_step = GFLOP_PER_IMAGE['hg4x128<-hg8x256'] * 1e9 * B
     achieved = flop_step / (ev_ms / args.steps * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
+    step_roof = {'achieved': round(achieved, 2), 'frac': round(achieved / peak, 4), 'unit': 'TFLOP/s',
+                 'note': 'one replay of the whole FPD step plan on one GPU: %.3f TFLOP algorithmic conv work (79.478 '
+                         'GFLOP/image x %d), HIP events on the launch stream: %.3f ms/step' % (flop_step / 1e12, B,
+                                                                                              ev_ms / args.steps)}
+    dom = dominant_kernel(step, R) if (rank == 0 and args.dtype == 'bf16') else None
+    if dom is not None:
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_bneck64.json')       # HBM bytes/launch from separate --pmc passes
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        k_ach = dom['flops'] / (dom['us'] * 1e-6) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': round(k_ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(k_ach / peak, 4), 'traffic': traffic, 'kernel': dom['name'],
+                    'avg_us': round(dom['us'], 2), 'flop_per_launch': dom['flops'],
+                    'algorithmic_bytes_per_launch': dom['bytes_algorithmic'],
+                    'note': 'dominant (kernel, shape) of the step: 17 launches/step; %d back-to-back launches timed with HIP '
+                            'events on the launch stream after the timed region; traffic = HBM bytes/launch from the committed '
+                            'rocprofv3 --pmc passes (profiles/), null if absent' % dom['launches'],
+                    'step': step_roof}
+    else:
+        roofline = {'bound': 'mfma', 'achieved': step_roof['achieved'], 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': step_roof['frac'], 'traffic': None, 'note': step_roof['note']}
     out = {
         'metric': 'images/sec FPD train step (4-stack HG student, 8-stack teacher) 256x256',
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -147,11 +197,7 @@ def main():
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay per phase',
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
-        'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / peak, 4), 'traffic': None,
-                     'note': 'one launch = one replay of the FPD step plan on one GPU: %.3f TFLOP algorithmic conv work '
-                             '(79.478 GFLOP/image x %d), timed with HIP events on the launch stream: %.3f ms/step' % (
-                                 flop_step / 1e12, B, ev_ms / args.steps)},
+        'roofline': roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         v, dt = cpu_baseline(args.cpu_batch, args.cpu_steps)

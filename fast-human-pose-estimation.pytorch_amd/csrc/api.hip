@@ -318,6 +318,16 @@ static int lane_priority() {            // FPD_LANE_PRIORITY=low|high|normal(def
     return prio;
 }
 
+static int side_streams() {              // FPD_SIDE_STREAMS=n: lanes 1.. share n physical streams (default: one stream per lane)
+    static int n = -1;
+    if (n < 0) {
+        const char* e = getenv("FPD_SIDE_STREAMS");
+        n = e ? atoi(e) : FPD_MAX_LANES;
+        if (n < 1) n = 1;
+    }
+    return n;
+}
+
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     FPD_REQUIRE(p && begin >= 0 && end <= (int)p->ops.size() && begin <= end, "plan_run: bad range [%d,%d)", begin, end);
     hipStream_t main_s = (hipStream_t)stream;
@@ -333,7 +343,7 @@ int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
         fpd_sched& sc = p->sched[i];
         hipStream_t st = main_s;
         if (sc.lane != 0) {
-            const int l = sc.lane;
+            const int l = 1 + (sc.lane - 1) % side_streams();
             if (!p->lanes[l]) {
                 FPD_CHECK_HIP(hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, lane_priority()));
                 FPD_CHECK_HIP(hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming));

@@ -7,7 +7,7 @@ R.lib()
 dev = torch.device('cuda', 0)
 N, P = 32, int(os.environ.get('P', '128'))
 C = 2 * P
-for HW in (64, 32, 16, 8, 4):
+for HW in ((int(os.environ['ONLY']),) if os.environ.get('ONLY') else (64, 32, 16, 8, 4)):
     A = E.Arenas(dev, R.BF16)
     sizes = {}
     def buf(arena, shape):
