@@ -20,6 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Before the HIP runtime loads (it is part of torch): a step keeps three streams busy (teacher, student chain, weight
+# gradients) and RCCL adds its own; with ROCm's default of 4 hardware queues two of the hot streams can end up sharing
+# one and serialise (measured: 14.4 -> 17.8 ms/step as soon as the process group exists).  See DESIGN.md section 4.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
@@ -86,7 +90,12 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--backend', default='mfma', choices=['mfma', 'naive'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graphs', action='store_true', help='launch kernel by kernel instead of replaying hipGraphs')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay each phase as a hipGraph instead of launching kernel by kernel (same GPU time; with more\n'
+                         'than 4 hardware queues ROCm 7.2 graph replay of multi-stream phases is pathologically slow)')
+    ap.add_argument('--no-graphs', action='store_true', help='(default; kept for older command lines)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group and use the all-reduce path even with one rank (path check)')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=2)
     args = ap.parse_args()
@@ -100,9 +109,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from fpd_amd import executor as E, runtime as R, synth
@@ -129,19 +140,21 @@ def main():
     step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W,
                           alpha=0.5, lr=2.5e-4, world_size=world)
     step.set_batch(x, tg, tw)                  # data resident in HBM before timing
-    allreduce = fdist.make_allreduce(dist) if world > 1 else None
-    if world > 1:
+    allreduce = fdist.make_allreduce(dist) if use_dist else None
+    if os.environ.get('FPD_FAKE_ALLREDUCE'):            # dev: deferred-Adam sequencing without any collective
+        allreduce = lambda g: (lambda: None)
+    if use_dist:
         fdist.broadcast_state(dist, student)
         fdist.broadcast_state(dist, teacher)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     step.run_pipelined(1, allreduce)                 # one eager step (sets one-time kernel attributes) before capture
-    if not args.no_graphs:
+    if args.graphs:
         step.enable_graphs()
     step.run_pipelined(args.warmup, allreduce)
     barrier()
@@ -156,7 +169,7 @@ def main():
     wall = time.time() - t0
     ev_ms = l.fpd_event_elapsed_ms(ev0, ev1)
     pose, kd, loss = step.losses()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -193,9 +206,9 @@ def main():
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'configs[1]: hourglass student S=4 F=128 + teacher S=8 F=256, 256x256, batch %d/GPU, '
-                               'fused FPD step incl. Adam, teacher forward one batch ahead on a 2nd stream%s' % (B, ' + RCCL all-reduce' if world > 1 else ''),
+                               'fused FPD step incl. Adam, teacher forward one batch ahead on a 2nd stream%s' % (B, ' + RCCL all-reduce' if use_dist else ''),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,
-                   'launch': 'eager' if args.no_graphs else 'hipGraph replay per phase',
+                   'launch': 'hipGraph replay per phase' if args.graphs else 'one native plan call per phase, kernels launched eagerly on 3 streams',
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
         'roofline': roofline,
     }
@@ -207,7 +220,7 @@ def main():
                                              args.cpu_batch, args.cpu_steps, dt)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -19,6 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before torch loads the HIP runtime; see bench.py / DESIGN.md section 4
 
 import torch  # noqa: E402
 import torch.utils.data  # noqa: E402

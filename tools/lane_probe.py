@@ -1,5 +1,6 @@
 """Dev probe: host enqueue time vs GPU time of the student/teacher phases, per lane configuration."""
 import os, sys, time
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import make_cfg
