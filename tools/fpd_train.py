@@ -47,17 +47,21 @@ def parse_args():
 class SyntheticPose(torch.utils.data.Dataset):
     """Seeded synthetic samples shaped like JointsDataset.__getitem__ (lib/dataset/JointsDataset.py:113-198)."""
 
+    POOL = 256          # distinct samples generated up front (one vectorised call); indices wrap around the pool
+
     def __init__(self, cfg, n, seed):
         self.n, self.seed = n, seed
         self.joints = cfg.MODEL.NUM_JOINTS
         self.image, self.heat, self.sigma = tuple(cfg.MODEL.IMAGE_SIZE), tuple(cfg.MODEL.HEATMAP_SIZE), cfg.MODEL.SIGMA
+        self.pool = synth.make_batch(seed * 1000003, min(n, self.POOL), self.joints, self.image, self.heat, self.sigma)
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
-        x, t, w = synth.make_batch(self.seed * 1000003 + i, 1, self.joints, self.image, self.heat, self.sigma)
-        return x[0], t[0], w[0], {'index': i}
+        x, t, w = self.pool
+        k = i % x.shape[0]
+        return x[k], t[k], w[k], {'index': i}
 
 
 def get_train_type(train_type, checkpoint):
