@@ -59,7 +59,7 @@ def dominant_kernel(step, R, launches=50):
     """Live timing of the dominant (kernel, shape): the teacher's first 64x64 fused Bottleneck, re-launched `launches`
     times back to back on the current stream between two HIP events.  Returns None if the teacher graph is unfused."""
     t = step.teacher
-    ops = [o for o in t.g.fwd if o.kind == 'bneck' and o.dims[1] == 64]
+    ops = [s_ for o in t.g.fwd for s_ in ((o.a, o.b) if o.kind == 'bneck2' else (o,)) if s_.kind == 'bneck' and s_.dims[1] == 64]
     if not ops:
         return None
     op = ops[0]

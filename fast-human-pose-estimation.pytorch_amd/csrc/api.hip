@@ -11,8 +11,10 @@
 
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
+int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_partials(const fpd_wgrad_t& a);
@@ -71,12 +73,12 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t);
 #undef SZ
     return -1;
 }
 
-int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
+static int validate_conv(const fpd_conv_t* a) {
     FPD_REQUIRE(a && a->x && a->w && a->y, "conv: null pointer");
     int rc = validate_conv_dims(a->N, a->H, a->W, a->C, a->K, a->R, a->S, a->stride, a->pad, a->P, a->Q);
     if (rc) return rc;
@@ -86,11 +88,37 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->bn.mode != FPD_BN_EVAL || (a->bn.running_mean && a->bn.running_var), "conv: eval-mode BN without running stats");
     FPD_REQUIRE(a->epi == FPD_EPI_PLAIN || (a->epi_x && a->epi_stats && a->epi_bn.mode == FPD_BN_TRAIN && a->epi_bn.stats),
                 "conv: BNRELU_BWD epilogue needs epi_x, epi_stats and a train-mode epi_bn");
-    hipStream_t st = (hipStream_t)stream;
-    rc = 1;
+    return 0;
+}
+
+static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
+    int rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
+    return rc;
+}
+
+int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
+    int rc = validate_conv(a);
+    if (rc) return rc;
+    rc = dispatch_conv(a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
+    FPD_REQUIRE(p, "conv_pair: null pointer");
+    int rc = validate_conv(&p->a);
+    if (rc) return rc;
+    rc = validate_conv(&p->b);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);
+    if (rc == 1) {                       // not pairable: same result from two launches
+        rc = dispatch_conv(&p->a, st);
+        if (rc == 0) rc = dispatch_conv(&p->b, st);
+    }
     return rc ? rc : check_launch();
 }
 
@@ -108,6 +136,23 @@ int fpd_bottleneck_fold(const fpd_bneck_t* a, fpd_stream_t stream) {
     if (rc) return rc;
     rc = fpd_bneck_fold_launch(*a, const_cast<float*>(a->folded), (hipStream_t)stream);
     if (rc == 1) return fpd_fail(-3, "bottleneck_fold: C=%d P=%d is outside the fused kernel's domain", a->C, a->P);
+    return rc ? rc : check_launch();
+}
+
+int fpd_bottleneck_forward_pair(const fpd_bneck_pair_t* p, fpd_stream_t stream) {
+    FPD_REQUIRE(p, "bottleneck_pair: null pointer");
+    const fpd_bneck_t* ab[2] = {&p->a, &p->b};
+    for (const fpd_bneck_t* a : ab) {
+        FPD_REQUIRE(a->x && a->y && a->w1 && a->w2 && a->w3 && a->x != a->y, "bottleneck_pair: null pointer or y aliases x");
+        FPD_REQUIRE((int64_t)a->N * a->H * a->W * a->C < ((int64_t)1 << 31), "bottleneck_pair: tensor too large for 32-bit indexing");
+        int rc = validate_bneck_bns(a);
+        if (rc) return rc;
+    }
+    int rc = fpd_bneck_fused_pair_launch(p->a, p->b, (hipStream_t)stream);
+    if (rc == 1) {                       // not pairable: same result from two launches
+        rc = fpd_bottleneck_forward(&p->a, stream);
+        return rc ? rc : fpd_bottleneck_forward(&p->b, stream);
+    }
     return rc ? rc : check_launch();
 }
 
@@ -211,7 +256,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_conv_t conv; fpd_bneck_t bneck; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -255,6 +300,8 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
     switch (op) {
         case FPD_OP_CONV: want = sizeof(fpd_conv_t); break;
         case FPD_OP_WGRAD: want = sizeof(fpd_wgrad_t); break;
+        case FPD_OP_CONV_PAIR: want = sizeof(fpd_conv_pair_t); break;
+        case FPD_OP_BNECK_PAIR: want = sizeof(fpd_bneck_pair_t); break;
         case FPD_OP_BNECK: case FPD_OP_BNECK_FOLD: want = sizeof(fpd_bneck_t); break;
         case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: want = sizeof(fpd_stem_t); break;
         case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
@@ -288,6 +335,8 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
     switch (o.type) {
         case FPD_OP_CONV: return fpd_conv_forward(&o.u.conv, s);
         case FPD_OP_WGRAD: return fpd_conv_wgrad(&o.u.wgrad, s);
+        case FPD_OP_CONV_PAIR: return fpd_conv_forward_pair(&o.u.pair, s);
+        case FPD_OP_BNECK_PAIR: return fpd_bottleneck_forward_pair(&o.u.bpair, s);
         case FPD_OP_BNECK: return fpd_bottleneck_forward(&o.u.bneck, s);
         case FPD_OP_BNECK_FOLD: return fpd_bottleneck_fold(&o.u.bneck, s);
         case FPD_OP_STEM_FWD: return fpd_stem_forward(&o.u.stem, s);

@@ -37,7 +37,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #ifdef FPD_BNECK_TIMING          // probe build only (tools/bneck_bench.py): cycle stamps of block 0 at the phase boundaries
-#define STAMP(i) do { if (tid == 0 && blockIdx.x == 0) stamps[i] = clock64(); } while (0)
+#define STAMP(i) do { if (tid == 0 && bid_in == 0) stamps[i] = clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -68,8 +68,10 @@ __device__ __forceinline__ void bneck_fold_tables(const fpd_bneck_t& a, float* o
 template <int P>
 __global__ void bneck_fold_kernel(const fpd_bneck_t a, float* out) { bneck_fold_tables<P>(a, out, threadIdx.x, blockDim.x); }
 
+// One 128-pixel tile (index bid_in of nblk) of fused Bottleneck `a`.
 template <int P>
-__global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int swz) {
+__device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int logW, const int swz, const int bid_in,
+                                                const int nblk) {
     constexpr int C = 2 * P;
     constexpr int LDX = 64 + 8;                 // phase-A staging rows (bf16 elements)
     constexpr int LD2 = P + 8;                  // a2 / a3 rows and [P][P] weight-tile rows
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a,
     const int M = a.N * H * W, GR = a.N * H;
     const int nrows = 128 >> logW, hrows = nrows + 2, WP = W + 2;
     const int zero_px = hrows * WP;
-    int bid = blockIdx.x;
-    if (swz) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // blocks of one XCD work on neighbouring tiles
+    int bid = bid_in;
+    if (swz) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);           // blocks of one XCD work on neighbouring tiles
     const int m0 = bid * 128, g0 = m0 >> logW;
 
     float* s_sc1 = reinterpret_cast<float*>(smem);
@@ -430,11 +432,52 @@ __global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a,
     });
 #ifdef FPD_BNECK_TIMING
     STAMP(6);
-    if (tid == 0 && blockIdx.x == 0)
+    if (tid == 0 && bid_in == 0)
         printf("bneck W=%d: setup %lld | phaseA %lld | tile0 %lld | B(9 taps) %lld | a3+C %lld | epilogue %lld | total %lld cycles\n",
                W, stamps[1] - stamps[0], stamps[2] - stamps[1], stamps[3] - stamps[2], stamps[4] - stamps[3],
                stamps[5] - stamps[4], stamps[6] - stamps[5], stamps[6] - stamps[0]);
 #endif
+}
+
+template <int P>
+__global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int swz) {
+    bneck_eval_body<P>(a, logW, swz, blockIdx.x, gridDim.x);
+}
+
+// Two independent fused Bottlenecks (the up-branch and the low-branch one of an hourglass level) in one launch.
+template <int P>
+__global__ __launch_bounds__(512, 1) void bneck_eval_pair_kernel(const fpd_bneck_t a, const fpd_bneck_t b, const int logWa,
+                                                                 const int logWb, const int nblk_a, const int nblk_b) {
+    if ((int)blockIdx.x < nblk_a) bneck_eval_body<P>(a, logWa, (nblk_a & 7) == 0, blockIdx.x, nblk_a);
+    else bneck_eval_body<P>(b, logWb, (nblk_b & 7) == 0, (int)blockIdx.x - nblk_a, nblk_b);
+}
+
+template <int P>
+size_t bneck_lds_bytes(int W) {
+    constexpr int C = 2 * P, LD2 = P + 8, LDX = 72, CW = 32 * (P / 64);
+    int logW = 0;
+    while ((1 << logW) < W) ++logW;
+    const int hrows = (128 >> logW) + 2, WP = W + 2;
+    const size_t r2 = std::max({(size_t)2 * P * LD2 * 2, (size_t)2 * (128 + P) * LDX * 2, (size_t)8 * 32 * (CW + 4) * 4});
+    return (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
+}
+
+template <int P>
+int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
+    const size_t lds = std::max(bneck_lds_bytes<P>(a.W), bneck_lds_bytes<P>(b.W));
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        configured = lds;
+    }
+    int la = 0, lb = 0;
+    while ((1 << la) < a.W) ++la;
+    while ((1 << lb) < b.W) ++lb;
+    const int na = cdiv(a.N * a.H * a.W, 128), nb = cdiv(b.N * b.H * b.W, 128);
+    hipLaunchKernelGGL((bneck_eval_pair_kernel<P>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, nb);
+    return 0;
 }
 
 template <int P>
@@ -470,6 +513,12 @@ int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st) {
     int logW = 0;
     while ((1 << logW) < a.W) ++logW;
     return a.P == 128 ? launch_bneck<128>(a, logW, st) : launch_bneck<64>(a, logW, st);
+}
+
+// 0 = both launched as one kernel, 1 = not pairable (caller launches them one by one)
+int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
+    if (!bneck_in_domain(a) || !bneck_in_domain(b) || a.P != b.P) return 1;
+    return a.P == 128 ? launch_bneck_pair<128>(a, b, st) : launch_bneck_pair<64>(a, b, st);
 }
 
 // folded tables ([3C + 4P] floats) for a.folded; 1 = P not supported

@@ -60,8 +60,10 @@ struct TapMma<float> {
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
+// One 128-pixel x 32*TN-channel tile of convolution `a`; (bx, by) = tile coordinates.  Shared by the single-conv
+// kernel and the pair kernel (two independent convolutions in one launch).
 template <typename T, int TN, int BK>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW, const int dbg) {
+__device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int logW, const int dbg, const int bx, const int by) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
     constexpr int LD = BK + 16 / (int)sizeof(T);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
     const int nrows = 128 >> logW, hrows = nrows + R - 1, WP = W + R - 1;
     const int zero_px = hrows * WP;              // 3 all-zero pixels behind the halo
     const int HP = zero_px + 3;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BNT;
+    const int m0 = bx * 128, n0 = by * BNT;
     const int g0 = m0 >> logW;
 
     // LDS: [BN tables | epilogue tables] then the tile region (halo + 2 weight buffers), which the epilogue reuses
@@ -238,6 +240,21 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
 }
 
 template <typename T, int TN, int BK>
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW, const int dbg) {
+    conv_tile_body<T, TN, BK>(a, logW, dbg, blockIdx.x, blockIdx.y);
+}
+
+// Two INDEPENDENT convolutions with the same tile configuration in one launch: pixel tiles [0, nbx_a) belong to `a`,
+// the rest to `b` (block-uniform choice; the descriptors live in kernel-argument memory).  Used for the two parallel
+// bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
+template <typename T, int TN, int BK>
+__global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const int logWa,
+                                                                const int logWb, const int nbx_a, const int dbg) {
+    if ((int)blockIdx.x < nbx_a) conv_tile_body<T, TN, BK>(a, logWa, dbg, blockIdx.x, blockIdx.y);
+    else conv_tile_body<T, TN, BK>(b, logWb, dbg, (int)blockIdx.x - nbx_a, blockIdx.y);
+}
+
+template <typename T, int TN, int BK>
 int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
     constexpr int LD = BK + 16 / (int)sizeof(T);
     const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
@@ -268,7 +285,68 @@ int launch_tile_tn(const fpd_conv_t& a, int logW, hipStream_t st) {
     return launch_tile<T, 1, BK>(a, logW, st);
 }
 
+static bool tile_domain(const fpd_conv_t& a) {
+    if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2 || (a.W & (a.W - 1)) != 0) return false;
+    if (a.C % 16 != 0 || a.C > 256) return false;
+    if (a.epi == FPD_EPI_BNRELU_BWD && a.K > FPD_MAXC) return false;
+    return true;
+}
+static int ilog2_rt(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
+
+template <typename T, int TN, int BK>
+int launch_pair(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
+    constexpr int LD = BK + 16 / (int)sizeof(T);
+    const int la = ilog2_rt(a.W), lb = ilog2_rt(b.W);
+    auto tile_bytes = [&](const fpd_conv_t& c, int lw) {
+        const int hrows = (128 >> lw) + c.R - 1, WP = c.W + c.R - 1;
+        return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)2 * 32 * TN * LD * sizeof(T);
+    };
+    const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
+    const size_t lds = (size_t)(2 * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) + std::max({tile_bytes(a, la), tile_bytes(b, lb), epi});
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        configured = lds;
+    }
+    const int nbx_a = cdiv(a.N * a.H * a.W, 128), nbx_b = cdiv(b.N * b.H * b.W, 128);
+    dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
+    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, b, la, lb, nbx_a, 0);
+    return 0;
+}
+
+template <typename T, int BK>
+int launch_pair_tn(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
+    const int mt = cdiv(a.N * a.H * a.W, 128) + cdiv(b.N * b.H * b.W, 128);
+    int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
+    while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;
+    if (tn == 4) return launch_pair<T, 4, BK>(a, b, st);
+    if (tn == 2) return launch_pair<T, 2, BK>(a, b, st);
+    return launch_pair<T, 1, BK>(a, b, st);
+}
+
 }  // namespace
+
+// Two independent convolutions in one launch; 1 = the pair is outside the domain (caller launches them one by one).
+// Requires both in the halo-tile domain with the same dtype, K (n-tiling), R and channel chunking.
+int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
+    if (!tile_domain(a) || !tile_domain(b)) return 1;
+    if (a.dtype != b.dtype || a.K != b.K || a.C != b.C || a.R != b.R) return 1;
+    const int nra = (128 >> ilog2_rt(a.W)) + a.R - 1, nrb = (128 >> ilog2_rt(b.W)) + b.R - 1;
+    if (a.dtype == FPD_BF16) {
+        const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
+        if (nra * a.W * (bk / 8) > 2048 || nrb * b.W * (bk / 8) > 2048) return 1;
+        if (bk == 64) return launch_pair_tn<bf16_t, 64>(a, b, st);
+        if (bk == 32) return launch_pair_tn<bf16_t, 32>(a, b, st);
+        return launch_pair_tn<bf16_t, 16>(a, b, st);
+    }
+    const int bk = (a.C % 32 == 0) ? 32 : 16;
+    if (nra * a.W * (bk / 4) > 2048 || nrb * b.W * (bk / 4) > 2048) return 1;
+    if (bk == 32) return launch_pair_tn<float, 32>(a, b, st);
+    return launch_pair_tn<float, 16>(a, b, st);
+}
 
 // returns 1 when the shape is outside this kernel's domain (caller tries the generic MFMA kernel next)
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st) {

@@ -203,6 +203,14 @@ class Lowering:
         return R.OP_MEMSET, s
 
     def op(self, op):
+        if op.kind == 'conv2':
+            s = R.ConvPairT()
+            s.a, s.b = self.conv(op.a)[1], self.conv(op.b)[1]
+            return R.OP_CONV_PAIR, s
+        if op.kind == 'bneck2':
+            s = R.BneckPairT()
+            s.a, s.b = self.bneck(op.a)[1], self.bneck(op.b)[1]
+            return R.OP_BNECK_PAIR, s
         if op.kind == 'bneck_fold':
             return R.OP_BNECK_FOLD, self.bneck(op.target)[1]
         return {'conv': self.conv, 'bneck': self.bneck, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
@@ -235,6 +243,7 @@ class GraphInstance:
         self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
                                   num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
                                   fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
+                                  pair_branches=env('FPD_PAIR', '1') != '0',
                                   lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
                                   wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
@@ -293,8 +302,9 @@ class GraphInstance:
         if entries:
             p.add(*self.low.wprep(entries))
         for op in g.fwd:                           # frozen fused Bottlenecks: fold BN + biases into tables once
-            if op.kind == 'bneck' and getattr(op, 'folded', None) is not None:
-                p.add(*self.low.op(G.Op('bneck_fold', target=op)))
+            for sub in ((op.a, op.b) if op.kind == 'bneck2' else (op,)):
+                if sub.kind == 'bneck' and getattr(sub, 'folded', None) is not None:
+                    p.add(*self.low.op(G.Op('bneck_fold', target=sub)))
         self.rng['prep'] = (b, len(p))
         b = len(p)
         for op in g.fwd:

@@ -91,6 +91,9 @@ class Op:
                 return []
             return [bn.gamma, bn.beta] + ([bn.stats] if bn.mode == 'train' else [bn.rmean, bn.rvar])
         k = self.kind
+        if k in ('conv2', 'bneck2'):       # two independent convolutions / fused Bottlenecks issued as one launch
+            (ra, wa), (rb, wb) = self.a.accesses(), self.b.accesses()
+            return ra + rb, wa + wb
         if k == 'conv':
             rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
             wr = [b(self.y), self.out_stats, self.epi_stats]
@@ -113,10 +116,14 @@ class Op:
         return [x for x in rd if x is not None], [x for x in wr if x is not None]
 
     def acts_in(self):
+        if self.kind in ('conv2', 'bneck2'):
+            return self.a.acts_in() + self.b.acts_in()
         return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
                 isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None]
 
     def acts_out(self):
+        if self.kind in ('conv2', 'bneck2'):
+            return self.a.acts_out() + self.b.acts_out()
         return [getattr(self, f) for f in ('y',) if isinstance(getattr(self, f, None), Act)] + \
                [a for a in getattr(self, 'extra_out', []) if a is not None]
 
@@ -251,13 +258,18 @@ class HourglassGraph:
     """Op lists for one (model, batch shape, train|eval) instance."""
 
     def __init__(self, params, num_feats, num_stacks, num_joints, batch, height, width, train, num_blocks=1,
-                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None, fuse_bneck=False):
+                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None, fuse_bneck=False, pair_branches=True):
         self.p = params
         self.F, self.S, self.J = num_feats, num_stacks, num_joints
         self.N, self.H, self.W = batch, height, width
         self.train, self.num_blocks, self.depth = train, num_blocks, depth
         self.wlp_is_master = wlp_is_master     # fp32 build: forward convs read the master weights directly
         self.fuse_bneck = fuse_bneck and not train   # frozen bf16 networks: whole Bottleneck in one launch
+        # The up-branch and the low-branch bottleneck of an hourglass level are independent and have the same channel
+        # shapes: their convolutions (and their data gradients) are issued pairwise as ONE launch ('conv2' ops), which
+        # takes ~100 launches off the latency-bound critical chain of a training step.
+        self.pair_branches = pair_branches
+        self._pair_op = None
         self.stats_size = 0
         self.fold_size = 0                     # folded BN tables of fused Bottlenecks ('fold' arena, fp32)
         self.wlp_size = 0
@@ -304,7 +316,7 @@ class HourglassGraph:
                   g[name + '.running_var'], g[name + '.num_batches_tracked'])
 
     # ---- forward primitives ----
-    def conv(self, x, name, bn=None, residual=None, pad=0):
+    def conv(self, x, name, bn=None, residual=None, pad=0, sink=None):
         wkey = name + '.weight'
         K, R, S, C = self.p[wkey].shape
         n, h, w, c = x.shape
@@ -317,7 +329,7 @@ class HourglassGraph:
         y.producer = op
         if bn is not None:
             self._use_bn(x, bn)
-        self.fwd.append(op)
+        (self.fwd if sink is None else sink).append(op)      # sink: collected by bottleneck_pair instead of issued
         return y
 
     def _use_bn(self, x, bn):
@@ -351,11 +363,11 @@ class HourglassGraph:
         assert a.shape[1] == 2 * b.shape[1] and a.shape[2] == 2 * b.shape[2] and a.shape[3] == b.shape[3]
         return self.ew('upadd_fwd', a.shape, a.shape, name, x=a, x2=b)
 
-    def bottleneck(self, x, p):
+    def bottleneck(self, x, p, sink=None):
         """hourglass.py:32-52 with bn_k+relu folded into conv_k's operand load."""
         c_in = x.shape[3]
         planes = self.p[p + 'conv1.weight'].shape[0]
-        if self.fuse_bneck and self.bneck_fusable(x.shape, planes) and (p + 'downsample.0.weight') not in self.p.entries:
+        if self._fused(x, p):
             n, h, w, _ = x.shape
             y = Act(x.shape, p + 'out')
             wb = (lambda k: self.p[k]) if self.wlp_is_master else (lambda k: self.wfwd[k])
@@ -366,14 +378,30 @@ class HourglassGraph:
                     b2=self.p[p + 'conv2.bias'], w3=wb(p + 'conv3.weight'), b3=self.p[p + 'conv3.bias'],
                     bn1=self._bn(p + 'bn1', c_in), bn2=self._bn(p + 'bn2', planes), bn3=self._bn(p + 'bn3', planes))
             y.producer = op
-            self.fwd.append(op)
+            (self.fwd if sink is None else sink).append(op)
             return y
-        t = self.conv(x, p + 'conv1', bn=self._bn(p + 'bn1', c_in))
-        t = self.conv(t, p + 'conv2', bn=self._bn(p + 'bn2', planes), pad=1)
+        t = self.conv(x, p + 'conv1', bn=self._bn(p + 'bn1', c_in), sink=sink)
+        t = self.conv(t, p + 'conv2', bn=self._bn(p + 'bn2', planes), pad=1, sink=sink)
         skip = x
         if (p + 'downsample.0.weight') in self.p.entries:
+            assert sink is None
             skip = self.conv(x, p + 'downsample.0')
-        return self.conv(t, p + 'conv3', bn=self._bn(p + 'bn3', planes), residual=skip)
+        return self.conv(t, p + 'conv3', bn=self._bn(p + 'bn3', planes), residual=skip, sink=sink)
+
+    def _fused(self, x, p):
+        planes = self.p[p + 'conv1.weight'].shape[0]
+        return (self.fuse_bneck and self.bneck_fusable(x.shape, planes) and
+                (p + 'downsample.0.weight') not in self.p.entries)
+
+    def bottleneck_pair(self, xa, pa, xb, pb):
+        """Two independent bottlenecks with equal channel shapes, convolution k of both issued as one 'conv2' op."""
+        la, lb = [], []
+        ya = self.bottleneck(xa, pa, sink=la)
+        yb = self.bottleneck(xb, pb, sink=lb)
+        assert len(la) == len(lb) and len(la) in (1, 3)
+        for oa, ob in zip(la, lb):
+            self.fwd.append(Op('conv2' if oa.kind == 'conv' else 'bneck2', a=oa, b=ob))
+        return ya, yb
 
     @staticmethod
     def bneck_fusable(shape, planes):
@@ -393,13 +421,22 @@ class HourglassGraph:
         nb = self.num_blocks
         # the up-branch is independent of the whole lower hourglass (a long chain of small, launch-latency-bound
         # kernels): it gets a lane of its own per level, so the two overlap on the GPU
-        outer = self._lane
-        if n > self.depth - self.lane_levels:
-            self._lane = n
-        up1 = self.residual_seq(x, q + '0.', nb)
-        self._lane = outer
-        low = self.maxpool(x, q + 'pool')
-        low = self.residual_seq(low, q + '1.', nb)
+        laned = n > self.depth - self.lane_levels
+        pa, pb = q + '0.0.', q + '1.0.'
+        n_, h_, w_, c_ = x.shape
+        if (self.pair_branches and nb == 1 and not laned and
+                self._fused(x, pa) == self._fused(Act((n_, h_ // 2, w_ // 2, c_)), pb) and     # both fused or both not
+                (pa + 'downsample.0.weight') not in self.p.entries and (pb + 'downsample.0.weight') not in self.p.entries):
+            low = self.maxpool(x, q + 'pool')
+            up1, low = self.bottleneck_pair(x, pa, low, pb)
+        else:
+            outer = self._lane
+            if laned:
+                self._lane = n
+            up1 = self.residual_seq(x, q + '0.', nb)
+            self._lane = outer
+            low = self.maxpool(x, q + 'pool')
+            low = self.residual_seq(low, q + '1.', nb)
         if n > 1:
             low = self.hour_glass(low, p, n - 1)
         else:
@@ -498,6 +535,16 @@ class HourglassGraph:
                 self._flush_wgrads()
             if op.kind == 'conv':
                 self._conv_backward(op)
+            elif op.kind == 'conv2':
+                # the two data-gradient convolutions go out as one launch too: the container is placed where the first
+                # of them is due (both output gradients are final here; the chains below it are independent)
+                c = self._pair_op = Op('conv2', a=None, b=None)
+                self._conv_backward(op.a)
+                self._conv_backward(op.b)
+                self._pair_op = None
+                if c.a is not None and c.b is None:                  # only one of them needs a data gradient
+                    c.a.lane = c.lane
+                    self.bwd[self.bwd.index(c)] = c.a
             elif op.kind == 'stem_fwd':
                 dy = op.y.grad
                 self.bwd.append(Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
@@ -515,6 +562,17 @@ class HourglassGraph:
             self.bwd.append(w)
         self._wg_pending = []
 
+    def _emit_dgrad(self, op):
+        c = self._pair_op
+        if c is None:
+            self.bwd.append(op)
+        elif c.a is None:
+            c.a = op
+            self.bwd.append(c)
+        else:
+            assert c.b is None
+            c.b = op
+
     def _conv_backward(self, op):
         dy = op.y.grad
         if dy is None:
@@ -531,15 +589,15 @@ class HourglassGraph:
         wb = self.wbwd[op.wkey]
         if op.bn is not None:
             def make(dz, add, bstats, op=op, dy=dy, x=x):
-                self.bwd.append(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=dz,
-                                   out_stats=None, bn=None, epi='bnrelu_bwd', epi_x=x, epi_bn=op.bn, epi_stats=bstats,
-                                   dims=ddims))
+                self._emit_dgrad(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=dz,
+                                    out_stats=None, bn=None, epi='bnrelu_bwd', epi_x=x, epi_bn=op.bn, epi_stats=bstats,
+                                    dims=ddims))
             self._bn_backward_contribution(x, op.bn, make)
         else:
             add, out = self._contribute(x)
-            self.bwd.append(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=out,
-                               out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims,
-                               lane=self._home(x) if add is not None else None))
+            self._emit_dgrad(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=out,
+                                out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims,
+                                lane=self._home(x) if add is not None else None))
 
     def _ew_backward(self, op):
         dy = op.y.grad

@@ -16,7 +16,7 @@ BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
- OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD) = range(13)
+ OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR) = range(15)
 MAX_STACKS = 8
 MAXC = 512
 
@@ -35,10 +35,18 @@ class ConvT(C.Structure):
                 ('out_stats', _vp), ('bn', BnT), ('epi_x', _vp), ('epi_bn', BnT), ('epi_stats', _vp)]
 
 
+class ConvPairT(C.Structure):
+    _fields_ = [('a', ConvT), ('b', ConvT)]
+
+
 class BneckT(C.Structure):
     _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('P', _i32), ('dtype', _i32), ('_pad', _i32 * 2),
                 ('x', _vp), ('y', _vp), ('w1', _vp), ('b1', _vp), ('w2', _vp), ('b2', _vp), ('w3', _vp), ('b3', _vp),
                 ('bn1', BnT), ('bn2', BnT), ('bn3', BnT), ('folded', _vp)]
+
+
+class BneckPairT(C.Structure):
+    _fields_ = [('a', BneckT), ('b', BneckT)]
 
 
 class WgradT(C.Structure):
@@ -96,13 +104,15 @@ class TableT(C.Structure):
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
-            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT}
+            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'fpd_conv_forward': (C.c_int, [C.POINTER(ConvT), _vp]),
+    'fpd_conv_forward_pair': (C.c_int, [C.POINTER(ConvPairT), _vp]),
     'fpd_bottleneck_forward': (C.c_int, [C.POINTER(BneckT), _vp]),
     'fpd_bottleneck_fold': (C.c_int, [C.POINTER(BneckT), _vp]),
+    'fpd_bottleneck_forward_pair': (C.c_int, [C.POINTER(BneckPairT), _vp]),
     'fpd_conv_wgrad': (C.c_int, [C.POINTER(WgradT), _vp]),
     'fpd_wgrad_num_partials': (C.c_int, [C.POINTER(WgradT)]),
     'fpd_wgrad_reduce': (C.c_int, [_vp, _i32, _i64, _vp]),

@@ -103,6 +103,14 @@ typedef struct {
     const float* folded;
 } fpd_bneck_t;
 
+/* Two INDEPENDENT convolutions issued as one launch (the parallel up-/low-branch bottlenecks of an hourglass level,
+ * hourglass.py:80-88, have identical channel shapes at full and half resolution): fpd_conv_forward_pair() runs them in a
+ * single kernel when both are in the halo-tile domain with equal dtype/C/K/R, else one after the other. */
+typedef struct { fpd_conv_t a, b; } fpd_conv_pair_t;
+
+/* Two independent frozen Bottlenecks as one launch (same P; else / outside the domain: an error, see fpd_bneck_t). */
+typedef struct { fpd_bneck_t a, b; } fpd_bneck_pair_t;
+
 /* Weight + bias gradient of the same conv (autograd of hourglass.py convs): dw[K][R][S][C] +=
  * sum_pixels dy * a(x), dbias[K] += sum_pixels dy.  fp32 atomics; caller zeroes dw/dbias. */
 typedef struct {
@@ -219,10 +227,12 @@ typedef struct {
 
 /* ---- single-op entry points (asynchronous on `stream`) ---- */
 int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream);
+int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream);
 /* fused frozen Bottleneck (three convs + three eval-mode BN+ReLU + residual), see fpd_bneck_t */
 int fpd_bottleneck_forward(const fpd_bneck_t* a, fpd_stream_t stream);
 /* writes a->folded (must be non-NULL) from a's BN / bias pointers; rerun whenever those parameters change */
 int fpd_bottleneck_fold(const fpd_bneck_t* a, fpd_stream_t stream);
+int fpd_bottleneck_forward_pair(const fpd_bneck_pair_t* p, fpd_stream_t stream);
 int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
 int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writes when a->partial is set */
 int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, int64_t max_elems, fpd_stream_t stream);
@@ -245,7 +255,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
-    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12
+    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

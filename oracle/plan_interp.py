@@ -260,7 +260,9 @@ def run_wprep(A, op):
 
 RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgrad': run_stem_wgrad, 'ew': run_ew,
        'bnupd': run_bnupd, 'loss': run_loss, 'wprep': run_wprep, 'bneck': run_bneck,
-       'bneck_fold': lambda A, op: None}       # device-side table preparation: no effect on the specification
+       'bneck_fold': lambda A, op: None,
+       'conv2': lambda A, op: (run_conv(A, op.a), run_conv(A, op.b)),
+       'bneck2': lambda A, op: (run_bneck(A, op.a), run_bneck(A, op.b))}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):

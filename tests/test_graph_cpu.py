@@ -197,15 +197,15 @@ def test_fused_bottleneck_graph_matches_unfused():
         table = G.ParamTable(keys)
         g = G.HourglassGraph(table, F_, S_, J, 1, 64, 64, train=False, fuse_bneck=fuse)
         kinds = {o.kind for o in g.fwd}
-        assert ('bneck' in kinds) == fuse
+        assert ('bneck' in kinds or 'bneck2' in kinds) == fuse
         act = G.plan_memory(g.fwd)
         A = U.make_arenas(g, table, act)
         U.load_params(A, table, sd)
         A.t['image'].copy_(x.reshape(-1))
         PI.run(A, g.fwd)
         outs.append(A.view(g.outputs[-1].buf).clone())
-    fused_ops = [o for o in G.HourglassGraph(G.ParamTable(keys), F_, S_, J, 1, 64, 64, train=False, fuse_bneck=True).fwd
-                 if o.kind == 'bneck']
+    fused_ops = [s_ for o in G.HourglassGraph(G.ParamTable(keys), F_, S_, J, 1, 64, 64, train=False, fuse_bneck=True).fwd
+                 for s_ in ((o.a, o.b) if o.kind == 'bneck2' else (o,)) if s_.kind == 'bneck']      # incl. paired ones
     assert len(fused_ops) == 9 and {o.dims[2] for o in fused_ops} == {16, 8, 4}      # 2x2 is outside the kernel's domain
     err = float((outs[0] - outs[1]).abs().max())
     assert err < 1e-4 * max(1.0, float(outs[0].abs().max())), err

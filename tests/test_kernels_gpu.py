@@ -487,3 +487,78 @@ def test_bottleneck_rejects_unsupported():
     a.y = torch.zeros(8 * 8 * 256, device='cuda').data_ptr()
     rc = R.lib().fpd_bottleneck_forward(a, None)
     assert rc != 0 and b'bn1' in R.lib().fpd_last_error()        # BN descriptors missing
+
+
+# ---- two independent convolutions in one launch (fpd_conv_forward_pair) --------------------------------------------
+PAIR_CASES = [
+    # N, H, W (of a; b runs at H/2 x W/2), C, K, R, bn_mode, epi
+    (2, 32, 32, 64, 64, 3, 'train', 'plain'),
+    (2, 16, 16, 128, 64, 1, 'train', 'plain'),
+    (3, 8, 8, 64, 128, 1, 'train', 'plain'),
+    (2, 16, 16, 64, 64, 3, None, 'bnrelu_bwd'),         # the paired data gradients of the backward pass
+    (2, 64, 64, 64, 64, 3, 'train', 'plain'),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', PAIR_CASES)
+def test_conv_pair(case, dtype):
+    """'conv2' op (one launch) vs the interpreter running the two convolutions one after the other."""
+    N, H, W, C, K, R, bnm, epi = case
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    b = Bench(dtype)
+    subs = []
+    rd = (lambda t: t.to(torch.bfloat16).float()) if dtype == 1 else (lambda t: t)
+    for (h, w) in ((H, W), (H // 2, W // 2)):
+        x_val = rnd(gen, N, h, w, C) + 0.3
+        x = b.act((N, h, w, C), x_val)
+        y = b.act((N, h, w, K), torch.zeros(N, h, w, K))
+        wt = b.buf('wlp', (K, R, R, C), rnd(gen, K, R, R, C, scale=(2.0 / (R * R * C)) ** 0.5))
+        bias = b.buf('param', (K,), 0.1 * rnd(gen, K)) if epi == 'plain' else None
+        bn = None
+        if bnm is not None:
+            bn = make_bn(b, gen, C, bnm)
+            bn.stats = b.buf('stats', (RS, 2, C), tensor_stats(rd(x_val)))
+            bn.count = N * h * w
+        kw = dict(epi='plain', epi_x=None, epi_bn=None, epi_stats=None,
+                  out_stats=b.buf('stats', (RS, 2, K), torch.zeros(RS, 2, K, dtype=torch.float64)))
+        if epi == 'bnrelu_bwd':
+            xf = rnd(gen, N, h, w, K)
+            ex = b.act((N, h, w, K), xf)
+            ebn = make_bn(b, gen, K, 'train', 'ebn')
+            ebn.stats = b.buf('stats', (RS, 2, K), tensor_stats(rd(xf)))
+            ebn.count = N * h * w
+            kw = dict(epi='bnrelu_bwd', epi_x=ex, epi_bn=ebn, out_stats=None,
+                      epi_stats=b.buf('stats', (RS, 2, K), torch.zeros(RS, 2, K, dtype=torch.float64)))
+        subs.append(G.Op('conv', x=x, w=wt, wkey='', bias=bias, bkey='', residual=None, y=y, bn=bn,
+                         dims=(N, h, w, C, K, R, R, 1, (R - 1) // 2, h, w), **kw))
+    op = G.Op('conv2', a=subs[0], b=subs[1])
+    b.realise()
+    b.run([op], 0)
+    for i, s in enumerate(subs):
+        b.compare(s.y, label='pair[%d] y %r' % (i, case), **TOL[dtype])
+        st = s.out_stats if s.out_stats is not None else s.epi_stats
+        b.compare(st, atol=TOL[dtype]['atol'] * N * s.dims[1] * s.dims[2], rtol=TOL[dtype]['rtol'], label='pair[%d] stats %r' % (i, case))
+
+
+def test_bottleneck_pair():
+    """'bneck2' op: two fused frozen Bottlenecks (full and half resolution) in one launch vs the specification."""
+    N, P = 3, 128
+    C = 2 * P
+    gen = torch.Generator().manual_seed(11)
+    b = Bench(1)
+    subs = []
+    for hw in (16, 8):
+        x = b.act((N, hw, hw, C), rnd(gen, N, hw, hw, C))
+        y = b.act((N, hw, hw, C), torch.zeros(N, hw, hw, C))
+        w1 = b.buf('wlp', (P, 1, 1, C), rnd(gen, P, 1, 1, C, scale=(2.0 / C) ** 0.5))
+        w2 = b.buf('wlp', (P, 3, 3, P), rnd(gen, P, 3, 3, P, scale=(2.0 / (9 * P)) ** 0.5))
+        w3 = b.buf('wlp', (C, 1, 1, P), rnd(gen, C, 1, 1, P, scale=(2.0 / P) ** 0.5))
+        b1, b2, b3 = (b.buf('param', (n,), 0.1 * rnd(gen, n)) for n in (P, P, C))
+        subs.append(G.Op('bneck', x=x, y=y, dims=(N, hw, hw, C, P), w1=w1, b1=b1, w2=w2, b2=b2, w3=w3, b3=b3,
+                         bn1=make_bn(b, gen, C, 'eval', 'bn1'), bn2=make_bn(b, gen, P, 'eval', 'bn2'),
+                         bn3=make_bn(b, gen, P, 'eval', 'bn3')))
+    b.realise()
+    b.run([G.Op('bneck2', a=subs[0], b=subs[1])], 0)
+    for i, s_ in enumerate(subs):
+        b.compare(s_.y, 3e-2, 2e-2, 'bneck pair[%d]' % i)
