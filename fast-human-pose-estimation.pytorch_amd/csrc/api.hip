@@ -26,6 +26,7 @@ int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
+int fpd_elementwise_pair_launch(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st);
 int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st);
 int fpd_adam_launch(const fpd_adam_t& a, hipStream_t st);
 int fpd_weight_prep_launch(const fpd_wprep_entry_t* table, int n, int64_t max_elems, int dtype, hipStream_t st);
@@ -73,7 +74,7 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t);
 #undef SZ
     return -1;
 }
@@ -217,6 +218,16 @@ int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream) {
     return rc ? rc : check_launch();
 }
 
+int fpd_elementwise_pair(const fpd_ew_pair_t* p, fpd_stream_t stream) {
+    FPD_REQUIRE(p && p->a.y && p->b.y, "elementwise_pair: null pointer");
+    int rc = fpd_elementwise_pair_launch(p->a, p->b, (hipStream_t)stream);
+    if (rc == 1) {
+        rc = fpd_elementwise_launch(p->a, (hipStream_t)stream);
+        if (rc == 0) rc = fpd_elementwise_launch(p->b, (hipStream_t)stream);
+    }
+    return rc ? rc : check_launch();
+}
+
 int fpd_loss(const fpd_loss_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->teacher && a->target && a->weight && a->losses, "loss: null pointer");
     int rc = fpd_loss_launch(*a, (hipStream_t)stream);
@@ -256,7 +267,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -302,6 +313,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_WGRAD: want = sizeof(fpd_wgrad_t); break;
         case FPD_OP_CONV_PAIR: want = sizeof(fpd_conv_pair_t); break;
         case FPD_OP_BNECK_PAIR: want = sizeof(fpd_bneck_pair_t); break;
+        case FPD_OP_EW_PAIR: want = sizeof(fpd_ew_pair_t); break;
         case FPD_OP_BNECK: case FPD_OP_BNECK_FOLD: want = sizeof(fpd_bneck_t); break;
         case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: want = sizeof(fpd_stem_t); break;
         case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
@@ -337,6 +349,7 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
         case FPD_OP_WGRAD: return fpd_conv_wgrad(&o.u.wgrad, s);
         case FPD_OP_CONV_PAIR: return fpd_conv_forward_pair(&o.u.pair, s);
         case FPD_OP_BNECK_PAIR: return fpd_bottleneck_forward_pair(&o.u.bpair, s);
+        case FPD_OP_EW_PAIR: return fpd_elementwise_pair(&o.u.epair, s);
         case FPD_OP_BNECK: return fpd_bottleneck_forward(&o.u.bneck, s);
         case FPD_OP_BNECK_FOLD: return fpd_bottleneck_fold(&o.u.bneck, s);
         case FPD_OP_STEM_FWD: return fpd_stem_forward(&o.u.stem, s);

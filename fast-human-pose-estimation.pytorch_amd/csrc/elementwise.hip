@@ -20,8 +20,9 @@ __device__ __forceinline__ void stv(T* p, const float* f) {
 }
 
 // One thread owns channel-vector `cv` (VEC channels) and walks pixels pl, pl+stride, ...
+// (bx, gx): this block's index and the number of blocks working on `a` (grid-stride over pixels)
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
+__device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const int gx) {
     constexpr int VEC = DT<T>::VEC;
     __shared__ float s_t0[FPD_MAXC], s_t1[FPD_MAXC], s_t2[FPD_MAXC], s_t3[FPD_MAXC];
     __shared__ float s_is[FPD_MAXC];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
                 s_t2[c] = (float)(b2 / cnt);                  // mean(dz * xhat)
                 s_t3[c] = mu;
                 s_is[c] = is;
-                if (blockIdx.x == 0) {   // gradients of the BN affine parameters fall out of the two sums
+                if (bx == 0) {   // gradients of the BN affine parameters fall out of the two sums
                     if (a.dgamma) a.dgamma[c] = (float)b2;
                     if (a.dbeta) a.dbeta[c] = (float)b1;
                 }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
     const bool do_stats = STATS ? (a.out_stats != nullptr) : BSTATS;
 
     if (active) {
-        for (int pix = blockIdx.x * PB + pl; pix < npix; pix += gridDim.x * PB) {
+        for (int pix = bx * PB + pl; pix < npix; pix += gx * PB) {
             float o[VEC];
             if (OP == FPD_EW_BNRELU_FWD) {
                 float v[VEC];
@@ -183,6 +184,16 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) {
 }
 
 template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) { ew_body<T, OP>(a, blockIdx.x, gridDim.x); }
+
+// two independent ops of the same kind in one launch (the BN-backward applies of the paired bottleneck chains)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_pair_kernel(const fpd_ew_t a, const fpd_ew_t b, const int ga) {
+    if ((int)blockIdx.x < ga) ew_body<T, OP>(a, blockIdx.x, ga);
+    else ew_body<T, OP>(b, (int)blockIdx.x - ga, (int)gridDim.x - ga);
+}
+
+template <typename T, int OP>
 int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     constexpr int VEC = DT<T>::VEC;
     const int VP = a.C / VEC, PB = 256 / VP;
@@ -194,6 +205,25 @@ int launch_ew(const fpd_ew_t& a, hipStream_t st) {
                                                                                                    : OP == FPD_EW_BNRELU_BWD_R;
     const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
     hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+
+template <typename T, int OP>
+int ew_grid(const fpd_ew_t& a) {
+    constexpr int VEC = DT<T>::VEC;
+    const int VP = a.C / VEC, PB = 256 / VP;
+    const bool half = (OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_MAXPOOL_BWD || OP == FPD_EW_SUMPOOL);
+    const int npix = a.N * (half ? a.H / 2 : a.H) * (half ? a.W / 2 : a.W);
+    const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
+                                                                                                   : OP == FPD_EW_BNRELU_BWD_R;
+    return std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
+}
+
+template <typename T>
+int launch_ew_pair(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st) {
+    if (a.op != FPD_EW_BN_BWD_APPLY) return 1;                 // the only pairing the graph builder emits
+    const int ga = ew_grid<T, FPD_EW_BN_BWD_APPLY>(a), gb = ew_grid<T, FPD_EW_BN_BWD_APPLY>(b);
+    hipLaunchKernelGGL((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
     return 0;
 }
 
@@ -213,6 +243,23 @@ int dispatch_ew(const fpd_ew_t& a, hipStream_t st) {
 }
 
 }  // namespace
+
+static int ew_check(const fpd_ew_t& a) {
+    const int vec = (a.dtype == FPD_BF16) ? 8 : 4;
+    if (a.C % vec != 0 || a.C > FPD_MAXC || a.C / vec > 128)
+        return fpd_fail(-3, "elementwise: C=%d must be a multiple of %d and <= %d", a.C, vec, FPD_MAXC);
+    return 0;
+}
+
+// 0 = launched as one kernel, 1 = not pairable (caller launches them one by one), <0 error
+int fpd_elementwise_pair_launch(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st) {
+    if (a.op != b.op || a.dtype != b.dtype) return 1;
+    int rc = ew_check(a);
+    if (rc) return rc;
+    rc = ew_check(b);
+    if (rc) return rc;
+    return a.dtype == FPD_BF16 ? launch_ew_pair<bf16_t>(a, b, st) : launch_ew_pair<float>(a, b, st);
+}
 
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st) {
     const int vec = (a.dtype == FPD_BF16) ? 8 : 4;

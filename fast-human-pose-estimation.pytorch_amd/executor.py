@@ -207,6 +207,10 @@ class Lowering:
             s = R.ConvPairT()
             s.a, s.b = self.conv(op.a)[1], self.conv(op.b)[1]
             return R.OP_CONV_PAIR, s
+        if op.kind == 'ew2':
+            s = R.EwPairT()
+            s.a, s.b = self.ew(op.a)[1], self.ew(op.b)[1]
+            return R.OP_EW_PAIR, s
         if op.kind == 'bneck2':
             s = R.BneckPairT()
             s.a, s.b = self.bneck(op.a)[1], self.bneck(op.b)[1]

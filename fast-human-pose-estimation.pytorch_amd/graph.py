@@ -91,7 +91,7 @@ class Op:
                 return []
             return [bn.gamma, bn.beta] + ([bn.stats] if bn.mode == 'train' else [bn.rmean, bn.rvar])
         k = self.kind
-        if k in ('conv2', 'bneck2'):       # two independent convolutions / fused Bottlenecks issued as one launch
+        if k in ('conv2', 'bneck2', 'ew2'):    # two independent convs / fused Bottlenecks / elementwise ops, one launch
             (ra, wa), (rb, wb) = self.a.accesses(), self.b.accesses()
             return ra + rb, wa + wb
         if k == 'conv':
@@ -116,13 +116,13 @@ class Op:
         return [x for x in rd if x is not None], [x for x in wr if x is not None]
 
     def acts_in(self):
-        if self.kind in ('conv2', 'bneck2'):
+        if self.kind in ('conv2', 'bneck2', 'ew2'):
             return self.a.acts_in() + self.b.acts_in()
         return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
                 isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None]
 
     def acts_out(self):
-        if self.kind in ('conv2', 'bneck2'):
+        if self.kind in ('conv2', 'bneck2', 'ew2'):
             return self.a.acts_out() + self.b.acts_out()
         return [getattr(self, f) for f in ('y',) if isinstance(getattr(self, f, None), Act)] + \
                [a for a in getattr(self, 'extra_out', []) if a is not None]
@@ -270,6 +270,7 @@ class HourglassGraph:
         # takes ~100 launches off the latency-bound critical chain of a training step.
         self.pair_branches = pair_branches
         self._pair_op = None
+        self._pair_ew = None
         self.stats_size = 0
         self.fold_size = 0                     # folded BN tables of fused Bottlenecks ('fold' arena, fp32)
         self.wlp_size = 0
@@ -515,9 +516,18 @@ class HourglassGraph:
             add, out = self._contribute(x)
             # x's gradient is consumed on the lane of x's producer: finishing it there keeps a side lane's last hop
             # off the main chain (main -> side -> main would cost two cross-stream dependencies)
-            self.bwd.append(Op('ew', op='bn_bwd_apply', dims=x.shape, x=x, x2=None, dy=pend['dz'], add=add, y=out,
-                               out_stats=None, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
-                               dbeta=self.p.grad(bn.name + '.bias'), bn=bn, lane=self._home(x)))
+            apply = Op('ew', op='bn_bwd_apply', dims=x.shape, x=x, x2=None, dy=pend['dz'], add=add, y=out,
+                       out_stats=None, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
+                       dbeta=self.p.grad(bn.name + '.bias'), bn=bn, lane=self._home(x))
+            c = self._pair_ew
+            if c is None or (apply.lane or 0) != 0:
+                self.bwd.append(apply)
+            elif c.a is None:                   # the paired chains' BN-backward applies also go out as one launch
+                c.a = apply
+                self.bwd.append(c)
+            else:
+                assert c.b is None
+                c.b = apply
             del self._bn_pending[key]
 
     def build_backward(self):
@@ -539,12 +549,14 @@ class HourglassGraph:
                 # the two data-gradient convolutions go out as one launch too: the container is placed where the first
                 # of them is due (both output gradients are final here; the chains below it are independent)
                 c = self._pair_op = Op('conv2', a=None, b=None)
+                e = self._pair_ew = Op('ew2', a=None, b=None)
                 self._conv_backward(op.a)
                 self._conv_backward(op.b)
-                self._pair_op = None
-                if c.a is not None and c.b is None:                  # only one of them needs a data gradient
-                    c.a.lane = c.lane
-                    self.bwd[self.bwd.index(c)] = c.a
+                self._pair_op = self._pair_ew = None
+                for cont in (c, e):
+                    if cont.a is not None and cont.b is None:        # only one of the two emitted this op
+                        cont.a.lane = cont.lane
+                        self.bwd[self.bwd.index(cont)] = cont.a
             elif op.kind == 'stem_fwd':
                 dy = op.y.grad
                 self.bwd.append(Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),

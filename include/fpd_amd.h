@@ -239,6 +239,9 @@ int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, in
 int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream);
 int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream);
 int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream);
+/* two independent elementwise ops of the same kind in one launch (else one after the other) */
+typedef struct { fpd_ew_t a, b; } fpd_ew_pair_t;
+int fpd_elementwise_pair(const fpd_ew_pair_t* p, fpd_stream_t stream);
 int fpd_loss(const fpd_loss_t* a, fpd_stream_t stream);
 int fpd_adam(const fpd_adam_t* a, fpd_stream_t stream);
 int fpd_weight_prep(const fpd_wprep_entry_t* table_dev, int32_t n_entries, int64_t max_elems, int32_t dtype,
@@ -255,7 +258,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
-    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14
+    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

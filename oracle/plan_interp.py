@@ -262,7 +262,8 @@ RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgr
        'bnupd': run_bnupd, 'loss': run_loss, 'wprep': run_wprep, 'bneck': run_bneck,
        'bneck_fold': lambda A, op: None,
        'conv2': lambda A, op: (run_conv(A, op.a), run_conv(A, op.b)),
-       'bneck2': lambda A, op: (run_bneck(A, op.a), run_bneck(A, op.b))}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
+       'bneck2': lambda A, op: (run_bneck(A, op.a), run_bneck(A, op.b)),
+       'ew2': lambda A, op: (run_ew(A, op.a), run_ew(A, op.b))}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):
