@@ -18,6 +18,7 @@
 // Rounding: each intermediate is rounded to bf16 once (after bias+BN+ReLU); the 3-launch path rounds the raw conv
 // output and again after BN.  oracle/plan_interp.py `run_bneck` is the specification of this op.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -68,10 +69,12 @@ __device__ __forceinline__ void bneck_fold_tables(const fpd_bneck_t& a, float* o
 template <int P>
 __global__ void bneck_fold_kernel(const fpd_bneck_t a, float* out) { bneck_fold_tables<P>(a, out, threadIdx.x, blockDim.x); }
 
-// One 128-pixel tile (index bid_in of nblk) of fused Bottleneck `a`.
+// Block bid_in of the nblk blocks assigned to fused Bottleneck `a`: persistent over its ntiles 128-pixel tiles
+// (tile = bid_in, bid_in + nblk, ...).  A grid smaller than the CU count leaves compute units free for the
+// latency-bound student kernels that run concurrently on another stream (a resident block owns its CU's LDS).
 template <int P>
 __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int logW, const int swz, const int bid_in,
-                                                const int nblk) {
+                                                const int nblk, const int ntiles) {
     constexpr int C = 2 * P;
     constexpr int LDX = 64 + 8;                 // phase-A staging rows (bf16 elements)
     constexpr int LD2 = P + 8;                  // a2 / a3 rows and [P][P] weight-tile rows
@@ -96,9 +99,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     const int M = a.N * H * W, GR = a.N * H;
     const int nrows = 128 >> logW, hrows = nrows + 2, WP = W + 2;
     const int zero_px = hrows * WP;
-    int bid = bid_in;
-    if (swz) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);           // blocks of one XCD work on neighbouring tiles
-    const int m0 = bid * 128, g0 = m0 >> logW;
+    int m0 = 0, g0 = 0;                          // first pixel / first image row of the current tile
 
     float* s_sc1 = reinterpret_cast<float*>(smem);
     float* s_sh1 = s_sc1 + C;
@@ -207,19 +208,27 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         });
     };
 
-    // first loads go out before anything else: everything below (tables, zero fill) hides under their latency
-    pass_addr(0);
-    static_for<NCH>([&](auto kcc) { a_load(kcc); });
-    if (npass > 1) pass_addr(1);
-
-    // ---- tables: folded by the host-side prep pass (a.folded) or here ----
+    // ---- tables (once per block): folded by the host-side prep pass (a.folded) or here ----
     if (a.folded != nullptr) {
         for (int v = tid; v < (3 * C + 4 * P) / 4; v += 512)
             reinterpret_cast<f32x4*>(s_sc1)[v] = reinterpret_cast<const f32x4*>(a.folded)[v];
     } else {
         bneck_fold_tables<P>(a, s_sc1, tid, 512);
     }
-    // zero border columns of every halo row + the zero pixels (whole LD2 rows, 16-byte vectors)
+
+    for (int tile = bid_in; tile < ntiles; tile += nblk) {
+    {
+        const int t = swz ? (tile & 7) * (ntiles >> 3) + (tile >> 3) : tile;   // tiles of one XCD are neighbours
+        m0 = t * 128;
+        g0 = m0 >> logW;
+    }
+    // first loads of the tile go out before anything else
+    pass_addr(0);
+    static_for<NCH>([&](auto kcc) { a_load(kcc); });
+    if (npass > 1) pass_addr(1);
+    __syncthreads();                             // tables visible; previous tile's epilogue is done with the LDS
+    // zero border columns of every halo row + the zero pixels (whole LD2 rows, 16-byte vectors); per tile, because
+    // the a3 image of the previous tile overwrote the first 128 rows
     {
         constexpr int VR = LD2 / 8;
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -229,7 +238,6 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             *reinterpret_cast<uint4*>(sA2 + px * LD2 + cv) = z;
         }
     }
-    __syncthreads();                             // tables visible to a_store
     STAMP(1);
 
     // =========================== phase A: conv1 over the halo rows ===========================
@@ -430,6 +438,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             }
         });
     });
+    }   // tile loop
 #ifdef FPD_BNECK_TIMING
     STAMP(6);
     if (tid == 0 && bid_in == 0)
@@ -440,16 +449,35 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
 }
 
 template <int P>
-__global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int swz) {
-    bneck_eval_body<P>(a, logW, swz, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int ntiles) {
+    bneck_eval_body<P>(a, logW, (ntiles & 7) == 0, blockIdx.x, gridDim.x, ntiles);
 }
 
 // Two independent fused Bottlenecks (the up-branch and the low-branch one of an hourglass level) in one launch.
 template <int P>
 __global__ __launch_bounds__(512, 1) void bneck_eval_pair_kernel(const fpd_bneck_t a, const fpd_bneck_t b, const int logWa,
-                                                                 const int logWb, const int nblk_a, const int nblk_b) {
-    if ((int)blockIdx.x < nblk_a) bneck_eval_body<P>(a, logWa, (nblk_a & 7) == 0, blockIdx.x, nblk_a);
-    else bneck_eval_body<P>(b, logWb, (nblk_b & 7) == 0, (int)blockIdx.x - nblk_a, nblk_b);
+                                                                 const int logWb, const int nblk_a, const int ntiles_a,
+                                                                 const int ntiles_b) {
+    if ((int)blockIdx.x < nblk_a) bneck_eval_body<P>(a, logWa, (ntiles_a & 7) == 0, blockIdx.x, nblk_a, ntiles_a);
+    else bneck_eval_body<P>(b, logWb, (ntiles_b & 7) == 0, (int)blockIdx.x - nblk_a, (int)gridDim.x - nblk_a, ntiles_b);
+}
+
+// grid cap of the persistent kernel (FPD_BNECK_BLOCKS): below the CU count so that concurrently running streams find
+// free compute units
+static int bneck_block_cap() {
+    static int cap = 0;
+    if (!cap) {
+        const char* e = getenv("FPD_BNECK_BLOCKS");
+        cap = e ? atoi(e) : 160;       // measured (r01, pipelined step): 1024/256/224/192/160/128 -> 13.56/13.86/13.37/13.30/13.21/13.23 ms
+        if (cap < 8) cap = 8;
+    }
+    return cap;
+}
+// blocks for `tiles` tiles under the cap, balanced so that every block runs the same number of rounds
+static int bneck_blocks(int tiles, int cap) {
+    if (tiles <= cap) return tiles;
+    const int rounds = cdiv(tiles, cap);
+    return cdiv(tiles, rounds);
 }
 
 template <int P>
@@ -475,8 +503,15 @@ int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st
     int la = 0, lb = 0;
     while ((1 << la) < a.W) ++la;
     while ((1 << lb) < b.W) ++lb;
-    const int na = cdiv(a.N * a.H * a.W, 128), nb = cdiv(b.N * b.H * b.W, 128);
-    hipLaunchKernelGGL((bneck_eval_pair_kernel<P>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, nb);
+    const int ta = cdiv(a.N * a.H * a.W, 128), tb = cdiv(b.N * b.H * b.W, 128);
+    int na = ta, nb = tb;
+    const int cap = bneck_block_cap();
+    if (ta + tb > cap) {                       // persistent: split the capped grid in proportion to the work
+        const int capb = std::max(1, (int)((int64_t)cap * tb / (ta + tb)));
+        nb = bneck_blocks(tb, capb);
+        na = bneck_blocks(ta, std::max(1, cap - nb));
+    }
+    hipLaunchKernelGGL((bneck_eval_pair_kernel<P>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, ta, tb);
     return 0;
 }
 
@@ -493,8 +528,8 @@ int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
-    const int nblk = cdiv(a.N * a.H * a.W, 128);
-    hipLaunchKernelGGL((bneck_eval_kernel<P>), dim3(nblk), dim3(512), lds, st, a, logW, (nblk % 8 == 0) ? 1 : 0);
+    const int ntiles = cdiv(a.N * a.H * a.W, 128);
+    hipLaunchKernelGGL((bneck_eval_kernel<P>), dim3(bneck_blocks(ntiles, bneck_block_cap())), dim3(512), lds, st, a, logW, ntiles);
     return 0;
 }
 
