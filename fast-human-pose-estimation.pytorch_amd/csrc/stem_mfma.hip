@@ -15,22 +15,44 @@ namespace {
 
 constexpr int NTAP = 147, KP = 160, LDA = KP + 8;     // padded taps; LDS row pitch (336 B)
 
-__device__ __forceinline__ void stage_patch(float* patch, const float* x, int n, int H, int W, int prow0, int prows,
-                                            int pcols, int tid, int nthreads) {
-    // patch[c][pr][pc] <- x[n][c][2*prow0 - 3 + pr][-3 + pc]   (zero outside the image); one wave per patch row,
-    // lanes along the row: coalesced, no per-element division
+// patch[c][pr][pc] <- x[n][c][2*prow0 - 3 + pr][-3 + pc]   (zero outside the image); one wave per patch row, lanes
+// along the row: coalesced, no per-element division.  All global loads of a wave are issued before the first LDS
+// store (a load -> store loop pays one memory latency per iteration: ~25 serial latencies per block, the old 314 us).
+template <int RMAX, int CMAX>       // rows per wave (3*prows over 4 waves), 64-lane steps per row (pcols)
+__device__ __forceinline__ void stage_patch_t(float* patch, const float* x, int n, int H, int W, int prow0, int prows,
+                                              int pcols, int tid, int nthreads) {
     const int lane = tid & 63, wv = tid >> 6, nw = nthreads >> 6;
-    for (int rr = wv; rr < 3 * prows; rr += nw) {
+    float v[RMAX][CMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int rr = wv + i * nw;
         const int c = rr / prows, pr = rr - c * prows;
         const int ih = 2 * prow0 - 3 + pr;
-        const bool rok = (unsigned)ih < (unsigned)H;
-        const float* src = x + ((size_t)(n * 3 + c) * H + (rok ? ih : 0)) * W;
-        float* dst = patch + rr * pcols;
-        for (int pc = lane; pc < pcols; pc += 64) {
-            const int iw = pc - 3;
-            dst[pc] = (rok && (unsigned)iw < (unsigned)W) ? src[iw] : 0.f;
+        const bool rok = rr < 3 * prows && (unsigned)ih < (unsigned)H;
+        const float* src = x + ((size_t)(n * 3 + (rok ? c : 0)) * H + (rok ? ih : 0)) * W;
+#pragma unroll
+        for (int j = 0; j < CMAX; ++j) {
+            const int iw = lane + 64 * j - 3;
+            v[i][j] = (rok && lane + 64 * j < pcols && (unsigned)iw < (unsigned)W) ? src[iw] : 0.f;
         }
     }
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int rr = wv + i * nw;
+        if (rr < 3 * prows) {
+#pragma unroll
+            for (int j = 0; j < CMAX; ++j)
+                if (lane + 64 * j < pcols) patch[rr * pcols + lane + 64 * j] = v[i][j];
+        }
+    }
+}
+__device__ __forceinline__ void stage_patch(float* patch, const float* x, int n, int H, int W, int prow0, int prows,
+                                            int pcols, int tid, int nthreads, int logQ) {
+    // Q = 128: 21 rows x 261 cols; 64: 27 x 133; 32: 39 x 69; 16: 63 x 37   (256 threads = 4 waves)
+    if (logQ == 7) stage_patch_t<6, 5>(patch, x, n, H, W, prow0, prows, pcols, tid, nthreads);
+    else if (logQ == 6) stage_patch_t<7, 3>(patch, x, n, H, W, prow0, prows, pcols, tid, nthreads);
+    else if (logQ == 5) stage_patch_t<10, 2>(patch, x, n, H, W, prow0, prows, pcols, tid, nthreads);
+    else stage_patch_t<16, 1>(patch, x, n, H, W, prow0, prows, pcols, tid, nthreads);
 }
 
 // A[pixel][tap] (bf16, two taps per dword) from the patch; tap = (r*7+s)*3+c, taps >= 147 are zero
@@ -77,14 +99,39 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const fpd_stem_t a, 
     const int g0 = m0 >> logQ;                                     // flattened (n, output row)
     const int n = g0 / P, prow0 = g0 - n * P;                      // P % rows == 0 (host-checked): one image per tile
 
-    for (int i = tid; i < 32 * TN * (KP / 2); i += 256) {          // weights [K][147] fp32 -> bf16 [32*TN][160]
-        const int k = i / (KP / 2), tp = (i - k * (KP / 2)) * 2;
-        const float w0 = (k < K && tp < NTAP) ? a.w[(size_t)k * NTAP + tp] : 0.f;
-        const float w1 = (k < K && tp + 1 < NTAP) ? a.w[(size_t)k * NTAP + tp + 1] : 0.f;
-        *reinterpret_cast<uint32_t*>(sW + k * LDA + tp) = f2bf_pk(w0, w1);
+    // weights [K][147] fp32 -> bf16 [32*TN][160]: the flat fp32 array is fetched as 16-byte vectors, all of them in
+    // flight before the patch loads are issued; converted and scattered to [k][tap] afterwards (K % 4 == 0: host-checked)
+    constexpr int NWV = (32 * TN * NTAP / 4 + 255) / 256;
+    float4 wv[NWV];
+    const int nwvec = K * NTAP / 4;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+        const int idx = tid + i * 256;
+        wv[i] = idx < nwvec ? reinterpret_cast<const float4*>(a.w)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    stage_patch(patch, a.x, n, a.H, a.W, prow0, prows, pcols, tid, 256);
-    __syncthreads();
+    for (int i = tid; i < 32 * TN * 8; i += 256) {                 // zero taps 144..159 of every row (147.. stay zero)
+        const int k = i >> 3;
+        *reinterpret_cast<uint32_t*>(sW + k * LDA + 144 + 2 * (i & 7)) = 0u;
+    }
+    for (int i = tid; i < (32 * TN - K) * (KP / 2); i += 256) {   // rows beyond K
+        const int k = K + i / (KP / 2), tp = (i % (KP / 2)) * 2;
+        *reinterpret_cast<uint32_t*>(sW + k * LDA + tp) = 0u;
+    }
+    stage_patch(patch, a.x, n, a.H, a.W, prow0, prows, pcols, tid, 256, logQ);
+    __syncthreads();                                                // zero fills above are ordered before the scatter
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nwvec) {
+            const float f[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fl = idx * 4 + e;
+                const int k = fl / NTAP, tp = fl - k * NTAP;
+                sW[k * LDA + tp] = f2bf(f[e]);
+            }
+        }
+    }
     build_im2col(sA, patch, s_off, logQ, pcols, zero_idx, tid, 256);
     __syncthreads();
 
@@ -142,7 +189,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a
         const int g0 = tile * rows;
         const int n = g0 / P, prow0 = g0 - n * P;
         __syncthreads();
-        stage_patch(patch, a.x, n, a.H, a.W, prow0, prows, pcols, tid, 256);
+        stage_patch(patch, a.x, n, a.H, a.W, prow0, prows, pcols, tid, 256, logQ);
         const int vpr = K / 8;                                     // 16-byte vectors per dy pixel
         for (int v = tid; v < 128 * vpr; v += 256) {
             const int px = v / vpr, cv = (v - px * vpr) * 8;
@@ -200,7 +247,7 @@ size_t patch_bytes(int logQ) {
 
 static bool stem_mfma_ok(const fpd_stem_t& a, int& logQ) {
     if (a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 64) return false;
-    if (a.Q > 128 || a.Q < 16 || (a.Q & (a.Q - 1)) != 0) return false;
+    if (a.Q > 128 || a.Q < 16 || (a.Q & (a.Q - 1)) != 0 || a.K % 4 != 0) return false;
     logQ = 0;
     while ((1 << logQ) < a.Q) ++logQ;
     if (a.P % (128 >> logQ) != 0) return false;
