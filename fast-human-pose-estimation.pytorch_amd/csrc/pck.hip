@@ -1,0 +1,83 @@
+// Per-step training metric on the device: heat-map arg-max + PCK@thr of the last student map against the target
+// (/root/reference/lib/core/inference.py:18-46 get_max_preds, lib/core/evaluate.py:16-71 calc_dists/dist_acc/accuracy;
+// the reference copies both tensors to the host and runs numpy every iteration, function.py:154-155).
+//   pck_kernel    one block per (sample, joint): arg-max of the NHWC prediction and of the NCHW target (first maximum
+//                 wins, like numpy.argmax), normalised distance, -> counts[joint] += {hit, valid}
+//   pck_finish    one block: per-joint accuracy = hits/valid (joints with no valid sample are skipped), average over the
+//                 remaining joints -> log[slot] = {avg_acc, cnt}; counts are zeroed for the next iteration
+#include "common.h"
+
+namespace {
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ ArgMax block_argmax(ArgMax m, ArgMax* s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax t;
+        t.v = __shfl_xor(m.v, o, 64);
+        t.i = __shfl_xor(m.i, o, 64);
+        m = better(m, t);
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    ArgMax r = s[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = better(r, s[w]);
+    __syncthreads();
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pck_kernel(const fpd_pck_t a) {
+    __shared__ ArgMax s[4];
+    const int b = blockIdx.x / a.J, j = blockIdx.x - b * a.J;
+    const int HW = a.H * a.W;
+    const T* out = reinterpret_cast<const T*>(a.out) + (size_t)b * HW * a.J + j;      // [B][H][W][J]
+    const float* tg = a.target + ((size_t)b * a.J + j) * HW;                           // [B][J][H][W]
+    ArgMax mp = {-3.4e38f, 0x7fffffff}, mg = {-3.4e38f, 0x7fffffff};
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        ArgMax t = {DT<T>::ld(out + (size_t)p * a.J), p};
+        mp = better(mp, t);
+        ArgMax g = {tg[p], p};
+        mg = better(mg, g);
+    }
+    mp = block_argmax(mp, s);
+    mg = block_argmax(mg, s);
+    if (threadIdx.x == 0) {
+        // get_max_preds: coordinates are zeroed where the maximum is not positive
+        const float px = mp.v > 0.f ? (float)(mp.i % a.W) : 0.f, py = mp.v > 0.f ? (float)(mp.i / a.W) : 0.f;
+        const float gx = mg.v > 0.f ? (float)(mg.i % a.W) : 0.f, gy = mg.v > 0.f ? (float)(mg.i / a.W) : 0.f;
+        if (gx > 1.f && gy > 1.f) {                     // calc_dists: only targets away from the top-left corner count
+            const float dx = (px - gx) / (a.W / 10.f), dy = (py - gy) / (a.H / 10.f);
+            const float d = sqrtf(dx * dx + dy * dy);
+            atomicAdd(a.counts + 2 * j + 1, 1.f);
+            if (d < a.thr) atomicAdd(a.counts + 2 * j, 1.f);
+        }
+    }
+}
+
+__global__ void pck_finish_kernel(const fpd_pck_t a) {
+    if (threadIdx.x != 0) return;
+    float sum = 0.f;
+    int cnt = 0;
+    for (int j = 0; j < a.J; ++j) {
+        const float hit = a.counts[2 * j], valid = a.counts[2 * j + 1];
+        if (valid > 0.f) { sum += hit / valid; ++cnt; }
+        a.counts[2 * j] = 0.f;
+        a.counts[2 * j + 1] = 0.f;
+    }
+    const long long k = *a.cursor;
+    float* dst = a.log + 2 * (k % a.log_slots);
+    dst[0] = cnt ? sum / cnt : 0.f;
+    dst[1] = (float)cnt;
+    *a.cursor = k + 1;
+}
+
+}  // namespace
+
+int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st) {
+    if (a.dtype == FPD_BF16) hipLaunchKernelGGL(pck_kernel<bf16_t>, dim3(a.B * a.J), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pck_kernel<float>, dim3(a.B * a.J), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(pck_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    return 0;
+}

@@ -458,6 +458,15 @@ class FusedFPDStep:
         self.student.rng['adam'] = (b, len(self.student.plan))
         self._dist_work = None
 
+    def enable_metric(self):
+        """Per-iteration PCK of the last student map against the target, on the device (lib.core.evaluate.DeviceAccuracy)."""
+        if getattr(self, 'metric', None) is None:
+            from .lib.core.evaluate import DeviceAccuracy
+            g, A = self.student.g, self.student.A
+            self.metric = DeviceAccuracy(self.B, self.J, self.hh, self.hw, self.dtype, self.student.state.device).bind(
+                A.ptr(g.outputs[-1].buf), A.tensor('target').data_ptr())
+        return self.metric
+
     def _add_loss(self, plan, slot):
         A, g = self.student.A, self.student.g
         plan.add(*self.student.low.memset('losses'))
@@ -526,6 +535,8 @@ class FusedFPDStep:
         s.run('prep')
         s.run('fwd')
         s.run('mid' if slot == 0 else 'mid1')
+        if getattr(self, 'metric', None) is not None:
+            self.metric.enqueue()
         s.run('bwd')
         if allreduce is not None:
             self._dist_work = allreduce(self.student.state.A.tensor('grad'))

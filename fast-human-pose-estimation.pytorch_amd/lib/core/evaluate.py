@@ -32,3 +32,38 @@ def accuracy(output, target, thr=0.5):
     cnt = int(has.sum().item())
     avg = float((acc_j * has.float()).sum().item() / cnt) if cnt else 0.0
     return torch.cat([torch.tensor([avg], device=output.device), acc_j]), avg, cnt, pred
+
+
+class DeviceAccuracy:
+    """The same metric as `accuracy()` computed by the HIP kernels of csrc/pck.hip on the NHWC prediction the fused step
+    keeps in its arena: `enqueue()` is asynchronous (one entry {avg_acc, cnt} per call appended to a device ring),
+    `drain()` returns the entries appended since the last drain -- the only point that synchronises."""
+
+    def __init__(self, batch, joints, height, width, dtype, device, slots=4096, thr=0.5):
+        from ... import runtime as R
+        self.R = R
+        self.slots = slots
+        self.counts = torch.zeros(joints * 2, dtype=torch.float32, device=device)
+        self.log = torch.zeros(slots * 2, dtype=torch.float32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)
+        self.read = 0
+        a = R.PckT()
+        a.B, a.J, a.H, a.W, a.dtype, a.log_slots, a.thr = batch, joints, height, width, dtype, slots, thr
+        a.counts, a.log, a.cursor = self.counts.data_ptr(), self.log.data_ptr(), self.cursor.data_ptr()
+        self.args = a
+
+    def bind(self, out_ptr, target_ptr):
+        self.args.out, self.args.target = out_ptr, target_ptr
+        return self
+
+    def enqueue(self, stream=None):
+        R = self.R
+        R.check(R.lib().fpd_pck(self.args, stream if stream is not None else R.current_stream()), 'fpd_pck')
+
+    def drain(self):
+        n = int(self.cursor.item())                       # synchronises with the stream the kernels ran on
+        assert n - self.read <= self.slots, 'metric ring overflow: drain() more often'
+        log = self.log.view(self.slots, 2).cpu()
+        out = [(float(log[k % self.slots, 0]), int(log[k % self.slots, 1])) for k in range(self.read, n)]
+        self.read = n
+        return out

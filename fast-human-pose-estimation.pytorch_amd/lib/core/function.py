@@ -69,6 +69,8 @@ def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_crite
             if step is not None:
                 step.flush()
             step = fused_step_for(model, tmodel, optimizer, inp.shape, alpha, world_size)
+            metric = step.enable_metric()              # PCK of every iteration, accumulated on the device
+            metric.drain()
             step.teacher_async(inp)                    # pipeline prologue: teacher forward of the first batch
         if isinstance(optimizer, FusedAdam):
             optimizer.sync_lr()
@@ -85,9 +87,8 @@ def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_crite
             pose, kd, loss = step.losses()                    # the only host sync of the loop
             n = inp.size(0)
             pose_losses.update(pose, n); kd_pose_losses.update(kd, n); losses.update(loss, n)
-            out = step.student.output_view(len(step.student.g.outputs) - 1).permute(0, 3, 1, 2).float()
-            _, avg_acc, cnt, pred = accuracy(out, step.student.A.tensor('target').view(target.shape))
-            acc.update(avg_acc, cnt)
+            for avg_acc, cnt in metric.drain():               # one entry per iteration since the last log line,
+                acc.update(avg_acc, cnt)                      # exactly what function.py:154-155 feeds its meter
             batch_time.update(time.time() - end)
             msg = 'Epoch: [{0}][{1}/{2}]\t' \
                   'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
@@ -113,4 +114,6 @@ def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_crite
         end = time.time()
     if step is not None:
         step.flush()
+        for avg_acc, cnt in metric.drain():
+            acc.update(avg_acc, cnt)
     return losses.avg

@@ -16,7 +16,7 @@ BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
- OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR) = range(16)
+ OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK) = range(17)
 MAX_STACKS = 8
 MAXC = 512
 
@@ -71,6 +71,11 @@ class EwPairT(C.Structure):
     _fields_ = [('a', EwT), ('b', EwT)]
 
 
+class PckT(C.Structure):
+    _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('dtype', _i32), ('log_slots', _i32), ('thr', C.c_float),
+                ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp)]
+
+
 class LossT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('S', _i32), ('dtype', _i32),
                 ('target_nchw', _i32), ('alpha', _f32), ('out', _vp * MAX_STACKS), ('dout', _vp * MAX_STACKS),
@@ -108,7 +113,7 @@ class TableT(C.Structure):
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
-            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT}
+            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -124,6 +129,7 @@ SYMBOLS = {
     'fpd_stem_wgrad': (C.c_int, [C.POINTER(StemT), _vp]),
     'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),
     'fpd_elementwise_pair': (C.c_int, [C.POINTER(EwPairT), _vp]),
+    'fpd_pck': (C.c_int, [C.POINTER(PckT), _vp]),
     'fpd_loss': (C.c_int, [C.POINTER(LossT), _vp]),
     'fpd_adam': (C.c_int, [C.POINTER(AdamT), _vp]),
     'fpd_weight_prep': (C.c_int, [_vp, _i32, _i64, _i32, _vp]),

@@ -254,11 +254,27 @@ int fpd_nchw_to_nhwc(const float* src, void* dst, int32_t N, int32_t C, int32_t 
 int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t dtype,
                      fpd_stream_t stream);
 
+/* Per-step training metric (lib/core/evaluate.py:16-71 accuracy, lib/core/inference.py:18-46 get_max_preds): heat-map
+ * arg-max of prediction and target, PCK@thr over the batch.  One call appends {avg_acc, cnt} (what the reference passes to
+ * its AverageMeter every iteration, function.py:154-155) to the device log ring at slot *cursor % log_slots and advances
+ * the cursor -- no host synchronisation; the host drains the ring when it prints a log line. */
+typedef struct {
+    int32_t B, J, H, W, dtype, log_slots;
+    float thr;             /* 0.5 in the reference */
+    int32_t _pad;
+    const void* out;       /* prediction [B,H,W,J] (NHWC, dtype) */
+    const float* target;   /* [B,J,H,W] fp32 (NCHW, as the loader delivers it) */
+    float* counts;         /* [J][2] workspace {hits, valid}, zero on entry, zeroed again on exit */
+    float* log;            /* [log_slots][2] */
+    long long* cursor;     /* device counter of appended entries */
+} fpd_pck_t;
+int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream);
+
 /* ---- execution plan: a recorded list of the ops above, replayed with one call ---- */
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
-    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15
+    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

@@ -562,3 +562,40 @@ def test_bottleneck_pair():
     b.run([G.Op('bneck2', a=subs[0], b=subs[1])], 0)
     for i, s_ in enumerate(subs):
         b.compare(s_.y, 3e-2, 2e-2, 'bneck pair[%d]' % i)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pck_metric(dtype):
+    """fpd_pck (arg-max + PCK@0.5 on the device) vs lib.core.evaluate.accuracy (torch restatement of the reference's
+    numpy metric, itself pinned against a numpy port in tests/test_host_cpu.py): identical (avg_acc, cnt), incl. ties,
+    all-non-positive maps (coordinates zeroed) and targets near the corner (excluded)."""
+    from fpd_amd.lib.core.evaluate import DeviceAccuracy, accuracy
+    B, J, H, W = 6, 16, 64, 64
+    gen = torch.Generator().manual_seed(3)
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    for trial in range(3):
+        tgt = torch.zeros(B, J, H, W)
+        out = (0.05 * torch.randn(B, J, H, W, generator=gen))
+        for b in range(B):
+            for j in range(J):
+                gx, gy = int(torch.randint(0, W, (1,), generator=gen)), int(torch.randint(0, H, (1,), generator=gen))
+                if (b + j) % 7 != 0:
+                    tgt[b, j, gy, gx] = 1.0                       # else: empty target (max 0 -> coordinates (0,0) -> not counted)
+                dx, dy = (int(torch.randint(-4, 5, (1,), generator=gen)) for _ in range(2))
+                px, py = min(max(gx + dx, 0), W - 1), min(max(gy + dy, 0), H - 1)
+                out[b, j, py, px] = 1.0
+                if (b * J + j) % 5 == 0:
+                    out[b, j, min(py + 1, H - 1), px] = 1.0       # tie: the first maximum must win
+                if (b * J + j) % 11 == 0:
+                    out[b, j] = -out[b, j].abs()                  # nothing positive: prediction collapses to (0, 0)
+        out_r = out.to(tdt).float()
+        _, avg, cnt, _ = accuracy(out_r, tgt)
+        dev = torch.device('cuda:0')
+        out_nhwc = out.permute(0, 2, 3, 1).contiguous().to(tdt).to(dev)
+        tgt_d = tgt.to(dev)
+        m = DeviceAccuracy(B, J, H, W, dtype, dev, slots=8).bind(out_nhwc.data_ptr(), tgt_d.data_ptr())
+        m.enqueue(); m.enqueue()
+        got = m.drain()
+        assert len(got) == 2 and got[0] == got[1], got            # counters are re-zeroed between calls
+        assert got[0][1] == cnt and abs(got[0][0] - avg) < 1e-6, (got[0], avg, cnt)
+        assert m.drain() == []
