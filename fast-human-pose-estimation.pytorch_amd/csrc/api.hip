@@ -15,6 +15,8 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
 int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st);
+int fpd_head_fused_launch(const fpd_head_t& a, hipStream_t st);
+int fpd_head_fold_launch(const fpd_head_t& a, float* out, hipStream_t st);
 int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st);
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
@@ -75,7 +77,7 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t); SZ(fpd_head_t);
 #undef SZ
     return -1;
 }
@@ -219,6 +221,30 @@ int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream) {
     return rc ? rc : check_launch();
 }
 
+static int validate_head(const fpd_head_t* a) {
+    FPD_REQUIRE(a && a->y0 && a->score && a->w_fc && a->w_score, "head: null pointer");
+    FPD_REQUIRE(a->next == nullptr || (a->x && a->w_fc2 && a->w_score2 && a->next != a->x && a->next != a->y0),
+                "head: next needs x, w_fc2, w_score2 and must not alias an input");
+    FPD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && (int64_t)a->N * a->H * a->W * a->C < ((int64_t)1 << 31), "head: bad dims");
+    FPD_REQUIRE(a->bn.mode == FPD_BN_EVAL && a->bn.relu && a->bn.gamma && a->bn.beta && a->bn.running_mean && a->bn.running_var,
+                "head: bn must be an eval-mode BN+ReLU with running statistics");
+    return 0;
+}
+int fpd_head_forward(const fpd_head_t* a, fpd_stream_t stream) {
+    int rc = validate_head(a);
+    if (rc) return rc;
+    rc = fpd_head_fused_launch(*a, (hipStream_t)stream);
+    if (rc == 1) return fpd_fail(-3, "head: C=%d J=%d dtype=%d is outside the fused kernel's domain", a->C, a->J, a->dtype);
+    return rc ? rc : check_launch();
+}
+int fpd_head_fold(const fpd_head_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->folded, "head_fold: null pointer");
+    FPD_REQUIRE(a->bn.mode == FPD_BN_EVAL && a->bn.gamma && a->bn.beta && a->bn.running_mean && a->bn.running_var, "head_fold: bn");
+    int rc = fpd_head_fold_launch(*a, const_cast<float*>(a->folded), (hipStream_t)stream);
+    if (rc == 1) return fpd_fail(-3, "head_fold: C=%d is outside the fused kernel's domain", a->C);
+    return rc ? rc : check_launch();
+}
+
 int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->out && a->target && a->counts && a->log && a->cursor, "pck: null pointer");
     FPD_REQUIRE(a->B > 0 && a->J > 0 && a->H > 0 && a->W > 0 && a->log_slots > 0, "pck: bad dims");
@@ -276,7 +302,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_head_t head; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -324,6 +350,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_BNECK_PAIR: want = sizeof(fpd_bneck_pair_t); break;
         case FPD_OP_EW_PAIR: want = sizeof(fpd_ew_pair_t); break;
         case FPD_OP_PCK: want = sizeof(fpd_pck_t); break;
+        case FPD_OP_HEAD: case FPD_OP_HEAD_FOLD: want = sizeof(fpd_head_t); break;
         case FPD_OP_BNECK: case FPD_OP_BNECK_FOLD: want = sizeof(fpd_bneck_t); break;
         case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: want = sizeof(fpd_stem_t); break;
         case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
@@ -361,6 +388,8 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
         case FPD_OP_BNECK_PAIR: return fpd_bottleneck_forward_pair(&o.u.bpair, s);
         case FPD_OP_EW_PAIR: return fpd_elementwise_pair(&o.u.epair, s);
         case FPD_OP_PCK: return fpd_pck(&o.u.pck, s);
+        case FPD_OP_HEAD: return fpd_head_forward(&o.u.head, s);
+        case FPD_OP_HEAD_FOLD: return fpd_head_fold(&o.u.head, s);
         case FPD_OP_BNECK: return fpd_bottleneck_forward(&o.u.bneck, s);
         case FPD_OP_BNECK_FOLD: return fpd_bottleneck_fold(&o.u.bneck, s);
         case FPD_OP_STEM_FWD: return fpd_stem_forward(&o.u.stem, s);

@@ -103,6 +103,18 @@ class Lowering:
         s.folded = p(getattr(op, 'folded', None))
         return R.OP_BNECK, s
 
+    def head(self, op):
+        s = R.HeadT()
+        (s.N, s.H, s.W, s.C, s.J) = op.dims
+        s.dtype = self.dtype
+        p = self.A.ptr
+        s.y0, s.x, s.score, s.next = p(_abuf(op.y0)), p(_abuf(op.x)), p(_abuf(op.score)), p(_abuf(op.next))
+        s.w_fc, s.b_fc, s.w_score, s.b_score = p(op.w_fc), p(op.b_fc), p(op.w_score), p(op.b_score)
+        s.w_fc2, s.b_fc2, s.w_score2, s.b_score2 = p(op.w_fc2), p(op.b_fc2), p(op.w_score2), p(op.b_score2)
+        s.bn = self.bn(op.bn)
+        s.folded = p(getattr(op, 'folded', None))
+        return R.OP_HEAD, s
+
     def wgrad(self, op):
         s = R.WgradT()
         (s.N, s.H, s.W, s.C, s.K, s.R, s.S, s.stride, s.pad, s.P, s.Q) = op.dims
@@ -215,6 +227,10 @@ class Lowering:
             s = R.BneckPairT()
             s.a, s.b = self.bneck(op.a)[1], self.bneck(op.b)[1]
             return R.OP_BNECK_PAIR, s
+        if op.kind == 'head':
+            return self.head(op)
+        if op.kind == 'head_fold':
+            return R.OP_HEAD_FOLD, self.head(op.target)[1]
         if op.kind == 'bneck_fold':
             return R.OP_BNECK_FOLD, self.bneck(op.target)[1]
         return {'conv': self.conv, 'bneck': self.bneck, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
@@ -247,7 +263,7 @@ class GraphInstance:
         self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
                                   num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
                                   fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
-                                  pair_branches=env('FPD_PAIR', '1') != '0',
+                                  pair_branches=env('FPD_PAIR', '1') != '0', fuse_head=env('FPD_FUSE_HEAD', '1') != '0',
                                   lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
                                   wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
@@ -309,6 +325,8 @@ class GraphInstance:
             for sub in ((op.a, op.b) if op.kind == 'bneck2' else (op,)):
                 if sub.kind == 'bneck' and getattr(sub, 'folded', None) is not None:
                     p.add(*self.low.op(G.Op('bneck_fold', target=sub)))
+                if sub.kind == 'head' and getattr(sub, 'folded', None) is not None:
+                    p.add(*self.low.op(G.Op('head_fold', target=sub)))
         self.rng['prep'] = (b, len(p))
         b = len(p)
         for op in g.fwd:

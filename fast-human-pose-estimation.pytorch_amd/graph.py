@@ -97,6 +97,10 @@ class Op:
         if k == 'conv':
             rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
             wr = [b(self.y), self.out_stats, self.epi_stats]
+        elif k == 'head':
+            rd = [b(self.y0), b(self.x), self.w_fc, self.b_fc, self.w_score, self.b_score, self.w_fc2, self.b_fc2,
+                  self.w_score2, self.b_score2] + bn_bufs(self.bn)
+            wr = [b(self.score), b(self.next)]
         elif k == 'bneck':
             rd = [b(self.x), self.w1, self.b1, self.w2, self.b2, self.w3, self.b3] + bn_bufs(self.bn1) + \
                 bn_bufs(self.bn2) + bn_bufs(self.bn3)
@@ -118,12 +122,16 @@ class Op:
     def acts_in(self):
         if self.kind in ('conv2', 'bneck2', 'ew2'):
             return self.a.acts_in() + self.b.acts_in()
+        if self.kind == 'head':
+            return [t for t in (self.y0, self.x) if t is not None]
         return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
                 isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None]
 
     def acts_out(self):
         if self.kind in ('conv2', 'bneck2', 'ew2'):
             return self.a.acts_out() + self.b.acts_out()
+        if self.kind == 'head':
+            return [t for t in (self.score, self.next) if t is not None]
         return [getattr(self, f) for f in ('y',) if isinstance(getattr(self, f, None), Act)] + \
                [a for a in getattr(self, 'extra_out', []) if a is not None]
 
@@ -258,13 +266,14 @@ class HourglassGraph:
     """Op lists for one (model, batch shape, train|eval) instance."""
 
     def __init__(self, params, num_feats, num_stacks, num_joints, batch, height, width, train, num_blocks=1,
-                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None, fuse_bneck=False, pair_branches=True):
+                 depth=4, wlp_is_master=True, lane_levels=None, wgrad_batch=None, fuse_bneck=False, pair_branches=True, fuse_head=True):
         self.p = params
         self.F, self.S, self.J = num_feats, num_stacks, num_joints
         self.N, self.H, self.W = batch, height, width
         self.train, self.num_blocks, self.depth = train, num_blocks, depth
         self.wlp_is_master = wlp_is_master     # fp32 build: forward convs read the master weights directly
         self.fuse_bneck = fuse_bneck and not train   # frozen bf16 networks: whole Bottleneck in one launch
+        self.fuse_head = fuse_head and self.fuse_bneck
         # The up-branch and the low-branch bottleneck of an hourglass level are independent and have the same channel
         # shapes: their convolutions (and their data gradients) are issued pairwise as ONE launch ('conv2' ops), which
         # takes ~100 launches off the latency-bound critical chain of a training step.
@@ -465,6 +474,29 @@ class HourglassGraph:
         for i in range(self.S):
             y = self.hour_glass(x, 'hg.%d.hg.' % i, self.depth)
             y = self.residual_seq(y, 'res.%d.' % i, self.num_blocks)
+            if self.fuse_head and ch == 256 and self.J == 16:
+                # frozen bf16 network: fc -> BN+ReLU -> score -> fc_ + score_ + residuals as ONE launch (head_fused.hip)
+                wb = (lambda k: self.p[k]) if self.wlp_is_master else (lambda k: self.wfwd[k])
+                last = i == self.S - 1
+                score = Act((y.shape[0], y.shape[1], y.shape[2], self.J), 'score.%d' % i)
+                score.persistent = True
+                nxt = None if last else Act(x.shape, 'stack%d.out' % i)
+                fold = Buf('fold', self.fold_size, (3 * ch + 32,), 'fold:head%d' % i)
+                self.fold_size += 3 * ch + 32
+                op = Op('head', y0=y, x=None if last else x, score=score, next=nxt, dims=(y.shape[0], y.shape[1], y.shape[2], ch, self.J),
+                        w_fc=wb('fc.%d.0.weight' % i), b_fc=self.p['fc.%d.0.bias' % i],
+                        w_score=wb('score.%d.weight' % i), b_score=self.p['score.%d.bias' % i],
+                        w_fc2=None if last else wb('fc_.%d.weight' % i), b_fc2=None if last else self.p['fc_.%d.bias' % i],
+                        w_score2=None if last else wb('score_.%d.weight' % i),
+                        b_score2=None if last else self.p['score_.%d.bias' % i],
+                        bn=self._bn('fc.%d.1' % i, ch), folded=fold)
+                score.producer = op
+                if nxt is not None:
+                    nxt.producer = op
+                self.fwd.append(op)
+                self.outputs.append(score)
+                x = nxt
+                continue
             y = self.conv(y, 'fc.%d.0' % i)
             fcbn = self._bn('fc.%d.1' % i, ch)
             score = self.conv(y, 'score.%d' % i, bn=fcbn)

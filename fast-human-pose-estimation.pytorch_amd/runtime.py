@@ -16,7 +16,7 @@ BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
- OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK) = range(17)
+ OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK, OP_HEAD, OP_HEAD_FOLD) = range(19)
 MAX_STACKS = 8
 MAXC = 512
 
@@ -71,6 +71,13 @@ class EwPairT(C.Structure):
     _fields_ = [('a', EwT), ('b', EwT)]
 
 
+class HeadT(C.Structure):
+    _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('J', _i32), ('dtype', _i32), ('_pad', _i32 * 2),
+                ('y0', _vp), ('x', _vp), ('score', _vp), ('next', _vp), ('w_fc', _vp), ('b_fc', _vp), ('w_score', _vp),
+                ('b_score', _vp), ('w_fc2', _vp), ('b_fc2', _vp), ('w_score2', _vp), ('b_score2', _vp), ('bn', BnT),
+                ('folded', _vp)]
+
+
 class PckT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('dtype', _i32), ('log_slots', _i32), ('thr', C.c_float),
                 ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp)]
@@ -113,7 +120,7 @@ class TableT(C.Structure):
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
-            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT}
+            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -130,6 +137,8 @@ SYMBOLS = {
     'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),
     'fpd_elementwise_pair': (C.c_int, [C.POINTER(EwPairT), _vp]),
     'fpd_pck': (C.c_int, [C.POINTER(PckT), _vp]),
+    'fpd_head_forward': (C.c_int, [C.POINTER(HeadT), _vp]),
+    'fpd_head_fold': (C.c_int, [C.POINTER(HeadT), _vp]),
     'fpd_loss': (C.c_int, [C.POINTER(LossT), _vp]),
     'fpd_adam': (C.c_int, [C.POINTER(AdamT), _vp]),
     'fpd_weight_prep': (C.c_int, [_vp, _i32, _i64, _i32, _vp]),

@@ -103,6 +103,32 @@ typedef struct {
     const float* folded;
 } fpd_bneck_t;
 
+/* The inter-stack head of a FROZEN hourglass stack in one launch (hourglass.py:134-137,184-190 with eval-mode BN):
+ *   a = relu(bn(fc(y0)));  score = score_conv(a);  next = x + fc_(a) + score_(score)        (all 1x1 convolutions)
+ * `a` stays in LDS (rounded to bf16 once); score is rounded to bf16 once (it is an output) and reused from LDS.
+ * next == NULL (last stack): only score is produced and w_fc2 / w_score2 / x may be NULL.
+ * Domain: dtype BF16, C == 256, J == 16; fpd_head_forward() returns an error outside it. */
+typedef struct {
+    int32_t N, H, W, C, J, dtype;
+    int32_t _pad[2];
+    const void* y0;        /* [N,H,W,C] output of the stack's last Bottleneck */
+    const void* x;         /* [N,H,W,C] the stack's input (residual), or NULL */
+    void* score;           /* [N,H,W,J] */
+    void* next;            /* [N,H,W,C] input of the next stack, or NULL */
+    const void* w_fc;      /* [C][1][1][C] */
+    const float* b_fc;
+    const void* w_score;   /* [J][1][1][C] */
+    const float* b_score;
+    const void* w_fc2;     /* fc_: [C][1][1][C] */
+    const float* b_fc2;
+    const void* w_score2;  /* score_: [C][1][1][J] */
+    const float* b_score2;
+    fpd_bn_t bn;           /* fc.1, EVAL */
+    const float* folded;   /* optional [3C+32] floats written by fpd_head_fold() */
+} fpd_head_t;
+int fpd_head_forward(const fpd_head_t* a, fpd_stream_t stream);
+int fpd_head_fold(const fpd_head_t* a, fpd_stream_t stream);
+
 /* Two INDEPENDENT convolutions issued as one launch (the parallel up-/low-branch bottlenecks of an hourglass level,
  * hourglass.py:80-88, have identical channel shapes at full and half resolution): fpd_conv_forward_pair() runs them in a
  * single kernel when both are in the halo-tile domain with equal dtype/C/K/R, else one after the other. */
@@ -274,7 +300,8 @@ int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream);
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
-    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16
+    FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16, FPD_OP_HEAD = 17,
+    FPD_OP_HEAD_FOLD = 18
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

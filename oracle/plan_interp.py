@@ -124,6 +124,24 @@ def run_bneck(A, op):
     _store(A, op.y, y)
 
 
+def run_head(A, op):
+    """Fused frozen inter-stack head (include/fpd_amd.h fpd_head_t; /root/reference/lib/models/hourglass.py:134-137,
+    184-190 in eval mode): a = relu(bn(fc(y0))) is rounded to the storage precision once and never stored; score is
+    rounded once (it is an output and the operand of score_)."""
+    def conv1x1(v, wbuf):
+        wt = A.view(wbuf).float().permute(0, 3, 1, 2)
+        return F.conv2d(v.permute(0, 3, 1, 2), wt, None).permute(0, 2, 3, 1)
+    y0 = _act(A, op.y0)
+    scale, shift, _, _ = _bn_coef(A, op.bn)
+    shift = torch.addcmul(shift, scale, A.view(op.b_fc))
+    a = _rnd(A, torch.addcmul(shift, conv1x1(y0, op.w_fc), scale).clamp_min(0))
+    score = _rnd(A, conv1x1(a, op.w_score) + A.view(op.b_score))
+    _store(A, op.score, score)
+    if op.next is not None:
+        out = conv1x1(a, op.w_fc2) + conv1x1(score, op.w_score2) + (A.view(op.b_fc2) + A.view(op.b_score2)) + _act(A, op.x)
+        _store(A, op.next, out)
+
+
 def run_wgrad(A, op):
     n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
     x = _prologue(A, _act(A, op.x), op.bn).permute(0, 3, 1, 2)
@@ -263,7 +281,8 @@ RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgr
        'bneck_fold': lambda A, op: None,
        'conv2': lambda A, op: (run_conv(A, op.a), run_conv(A, op.b)),
        'bneck2': lambda A, op: (run_bneck(A, op.a), run_bneck(A, op.b)),
-       'ew2': lambda A, op: (run_ew(A, op.a), run_ew(A, op.b))}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
+       'ew2': lambda A, op: (run_ew(A, op.a), run_ew(A, op.b)),
+       'head': run_head, 'head_fold': lambda A, op: None}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):

@@ -212,3 +212,29 @@ def test_fused_bottleneck_graph_matches_unfused():
     # training graphs never fuse (train-mode BN needs batch statistics between the convs)
     gt = G.HourglassGraph(G.ParamTable(keys), F_, S_, J, 1, 64, 64, train=True, fuse_bneck=True)
     assert all(o.kind != 'bneck' for o in gt.fwd)
+
+
+def test_fused_head_graph_matches_unfused():
+    """F=256, J=16 frozen network: the 'head' op (fc -> BN+ReLU -> score -> fc_ + score_ + residuals in one launch) wired
+    by the builder computes what the four-conv graph computes (fp32: rounding noise only), for inner stacks and the last."""
+    from oracle import fpd_ref
+    F_, S_, J = 256, 2, 16
+    keys = hourglass_ref.hourglass_keys(F_, S_, J)
+    sd = fpd_ref.synth_state_dict(keys, 9)
+    x, _, _ = fpd_ref.synth_batch(6, 1, J, image_size=(64, 64), heatmap_size=(16, 16))
+    outs = []
+    for fuse in (False, True):
+        table = G.ParamTable(keys)
+        g = G.HourglassGraph(table, F_, S_, J, 1, 64, 64, train=False, fuse_bneck=fuse)
+        heads = [o for o in g.fwd if o.kind == 'head']
+        assert len(heads) == (S_ if fuse else 0)
+        if fuse:
+            assert heads[0].next is not None and heads[-1].next is None
+        act = G.plan_memory(g.fwd)
+        A = U.make_arenas(g, table, act)
+        U.load_params(A, table, sd)
+        A.t['image'].copy_(x.reshape(-1))
+        PI.run(A, g.fwd)
+        outs.append([A.view(o.buf).clone() for o in g.outputs])
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(a.abs().max()))

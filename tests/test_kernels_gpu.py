@@ -599,3 +599,37 @@ def test_pck_metric(dtype):
         assert len(got) == 2 and got[0] == got[1], got            # counters are re-zeroed between calls
         assert got[0][1] == cnt and abs(got[0][0] - avg) < 1e-6, (got[0], avg, cnt)
         assert m.drain() == []
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, True), (3, 8, 8, True), (2, 16, 16, False), (1, 64, 64, True)])
+def test_head_fused(case):
+    """fpd_head_forward vs its CPU specification (oracle/plan_interp.run_head), inner stack (next) and last stack."""
+    N, H, W, has_next = case
+    C, J = 256, 16
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    b = Bench(1)
+    y0 = b.act((N, H, W, C), rnd(gen, N, H, W, C))
+    x = b.act((N, H, W, C), rnd(gen, N, H, W, C)) if has_next else None
+    score = b.act((N, H, W, J), torch.zeros(N, H, W, J))
+    nxt = b.act((N, H, W, C), torch.zeros(N, H, W, C)) if has_next else None
+    w_fc = b.buf('wlp', (C, 1, 1, C), rnd(gen, C, 1, 1, C, scale=(2.0 / C) ** 0.5))
+    w_sc = b.buf('wlp', (J, 1, 1, C), rnd(gen, J, 1, 1, C, scale=(1.0 / C) ** 0.5))
+    w_fc2 = b.buf('wlp', (C, 1, 1, C), rnd(gen, C, 1, 1, C, scale=(1.0 / C) ** 0.5)) if has_next else None
+    w_sc2 = b.buf('wlp', (C, 1, 1, J), rnd(gen, C, 1, 1, J, scale=(1.0 / J) ** 0.5)) if has_next else None
+    b_fc, b_sc = b.buf('param', (C,), 0.1 * rnd(gen, C)), b.buf('param', (J,), 0.1 * rnd(gen, J))
+    b_fc2 = b.buf('param', (C,), 0.1 * rnd(gen, C)) if has_next else None
+    b_sc2 = b.buf('param', (C,), 0.1 * rnd(gen, C)) if has_next else None
+    op = G.Op('head', y0=y0, x=x, score=score, next=nxt, dims=(N, H, W, C, J), w_fc=w_fc, b_fc=b_fc, w_score=w_sc, b_score=b_sc,
+              w_fc2=w_fc2, b_fc2=b_fc2, w_score2=w_sc2, b_score2=b_sc2, bn=make_bn(b, gen, C, 'eval', 'fcbn'))
+    for fold in (False, True):
+        ops = [op]
+        if fold:
+            op.folded = b.buf('fold', (3 * C + 32,), torch.full((3 * C + 32,), float('nan')))
+            ops = [G.Op('head_fold', target=op), op]
+        b.realise()
+        b.run(ops, 0)
+        b.compare(score, 3e-2, 2e-2, 'head score %r fold=%s' % (case, fold))
+        if has_next:
+            b.compare(nxt, 3e-2, 2e-2, 'head next %r fold=%s' % (case, fold))
+            spec, got = b.cpu.view(nxt.buf).float(), b.gpu.view(nxt.buf).float().cpu()
+            assert float((got - spec).norm() / spec.norm()) < 3e-3
