@@ -204,7 +204,8 @@ def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
 
 
 WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), (1, 9, 7, 16, 16, 3, 1, False),
-               (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True)]
+               (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True),
+               (32, 4, 4, 64, 64, 3, 1, True), (32, 8, 8, 64, 64, 3, 1, True), (32, 4, 4, 128, 64, 1, 0, True)]   # deepest hourglass levels
 
 
 @pytest.mark.parametrize('backend', BACKENDS + ['partials'])
