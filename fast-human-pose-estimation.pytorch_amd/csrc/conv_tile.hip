@@ -250,8 +250,11 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
 template <typename T, int TN, int BK>
 __global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const int logWa,
                                                                 const int logWb, const int nbx_a, const int dbg) {
-    if ((int)blockIdx.x < nbx_a) conv_tile_body<T, TN, BK>(a, logWa, dbg, blockIdx.x, blockIdx.y);
-    else conv_tile_body<T, TN, BK>(b, logWb, dbg, (int)blockIdx.x - nbx_a, blockIdx.y);
+    // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
+    // launch ends with a's normal tail instead of a's tail followed by b's
+    const int nbx_b = (int)gridDim.x - nbx_a;
+    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK>(b, logWb, dbg, blockIdx.x, blockIdx.y);
+    else conv_tile_body<T, TN, BK>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
 }
 
 template <typename T, int TN, int BK>

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) { ew_body<T, 
 // two independent ops of the same kind in one launch (the BN-backward applies of the paired bottleneck chains)
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void ew_pair_kernel(const fpd_ew_t a, const fpd_ew_t b, const int ga) {
-    if ((int)blockIdx.x < ga) ew_body<T, OP>(a, blockIdx.x, ga);
-    else ew_body<T, OP>(b, (int)blockIdx.x - ga, (int)gridDim.x - ga);
+    const int gb = (int)gridDim.x - ga;                       // b (half resolution) first: no tail of small blocks
+    if ((int)blockIdx.x < gb) ew_body<T, OP>(b, blockIdx.x, gb);
+    else ew_body<T, OP>(a, (int)blockIdx.x - gb, ga);
 }
 
 template <typename T, int OP>
