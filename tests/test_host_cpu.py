@@ -148,3 +148,12 @@ def test_data_parallel_gradient_is_mean_of_shard_gradients():
         ref = ref + torch.cat([g[k].reshape(-1) for k in fpd_ref.param_names(s_sd)]) / world
     # same arithmetic, different CPU thread counts -> summation-order noise only (gradients here reach |g| ~ 40)
     np.testing.assert_allclose(got, ref.numpy(), rtol=1e-4, atol=2e-6 * float(ref.abs().max()))
+
+
+def test_hrnet_factory_fails_loudly():
+    """MODEL.NAME pose_hrnet resolves (like the reference's eval('models.' + NAME + '.get_pose_net')) but the path is not
+    built: a clear error, never a silent torch fallback."""
+    from fpd_amd.lib import models
+    from fpd_amd.runtime import FpdError
+    with pytest.raises(FpdError, match='HRNet'):
+        eval('models.pose_hrnet.get_pose_net')(None, is_train=True)
