@@ -1,0 +1,111 @@
+"""Parity at BASELINE.json's FULL size (configs[1]: student hourglass S=4 F=128, teacher S=8 F=256, 256x256, batch 32).
+
+The CPU oracle needs ~20 s per step at this size, so the checker here is the SAME oracle code (oracle/hourglass_ref.py,
+oracle/fpd_ref.py -- the restatement pinned against the reference's golden vectors by tests/test_oracle_golden.py) executed
+on CUDA tensors: plain torch fp32 ops (MIOpen convolutions, torch batch_norm, autograd), an implementation independent of
+this package's kernels.  The product side is the fp32 parity build of the fused step, driven through the C ABI.
+The referee is the oracle in fp64 on the CPU (student step: ~40 s; teacher: two samples, eval BN is per-sample).  Criterion as in
+tests/_cases.assert_parity: at this depth fp32 rounding is amplified to ~4e-4 on the O(1) teacher map and to percents on
+early-layer gradients, for MIOpen as for us -- we must never be less accurate than 1.5x the torch fp32 evaluation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fpd_ref, hourglass_ref
+
+pytestmark = pytest.mark.gpu
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _cfg(feats, stacks, joints, dtype):
+    return AD(MODEL=AD(NUM_JOINTS=joints, DTYPE=dtype, EXTRA=AD(NUM_FEATURES=feats, NUM_STACKS=stacks, NUM_BLOCKS=1)))
+
+
+def test_full_size_fpd_step_matches_the_oracle_run_on_cuda():
+    from fpd_amd import executor as E
+    from fpd_amd.lib.models import hourglass
+    dev = torch.device('cuda', 0)
+    B, J, H, W = 32, 16, 256, 256
+    s_keys, t_keys = hourglass_ref.hourglass_keys(128, 4, J), hourglass_ref.hourglass_keys(256, 8, J)
+    s_sd, t_sd = fpd_ref.synth_state_dict(s_keys, 1), fpd_ref.synth_state_dict(t_keys, 2)
+    x, tg, tw = fpd_ref.synth_batch(100, B, J, (W, H), (W // 4, H // 4))
+    # give the random teacher sane eval statistics (same procedure as the golden generator), on the GPU
+    t_cu = {k: v.to(dev) for k, v in t_sd.items()}
+    with torch.no_grad():
+        fpd_ref.calibrate_bn(t_cu, 8, [fpd_ref.synth_batch(200 + i, 8, J, (W, H), (W // 4, H // 4))[0].to(dev) for i in range(2)])
+    t_sd = {k: v.cpu() for k, v in t_cu.items()}
+
+    student = hourglass.get_pose_net(_cfg(128, 4, J, 'fp32'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(256, 8, J, 'fp32'), is_train=False)
+    student.load_state_dict(s_sd, strict=True)
+    teacher.load_state_dict(t_sd, strict=True)
+    student, teacher = student.to(dev), teacher.to(dev)
+    step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5)
+    step.set_batch(x, tg, tw)
+    step.teacher_async(x)
+    # run the phases by hand so that the gradients can be read before Adam consumes them
+    s = step.student
+    torch.cuda.current_stream().wait_event(step.ev_t[0])
+    s.run('prep'); s.run('fwd'); s.run('mid'); s.run('bwd')
+    torch.cuda.synchronize()
+    ours_maps = [s.output_view(i).permute(0, 3, 1, 2).float().cpu() for i in range(4)]
+    ours_tmap = step.tmap[0].view(B, H // 4, W // 4, J).permute(0, 3, 1, 2).float().cpu()
+    pose, kd, loss = step.losses()
+    student._attach_grads()
+    ours_grads = {k: p.grad.detach().cpu() for k, p in student.named_parameters()}
+
+    # ---- checker 1: the oracle on CUDA (torch fp32 / MIOpen), student step against the SAME teacher map ----
+    tmap_fixed = ours_tmap.clone()
+
+    def student_step(sd, xin, tgt, wgt, tmap):
+        names = fpd_ref.param_names(sd)
+        for k in names:
+            sd[k].requires_grad_(True)
+        outs = hourglass_ref.hourglass_forward(sd, xin, 4, train=True)
+        pose_, kd_, loss_ = fpd_ref.fpd_losses(outs, tmap, tgt, wgt, 0.5)
+        loss_.backward()
+        return [o.detach() for o in outs], (float(pose_), float(kd_), float(loss_)), {k: sd[k].grad.detach() for k in names}
+
+    s_cu = {k: v.to(dev) for k, v in s_sd.items()}
+    m_maps, m_loss, m_grads = student_step(s_cu, x.to(dev), tg.to(dev), tw.to(dev), tmap_fixed.to(dev))
+    with torch.no_grad():
+        m_tmap = hourglass_ref.hourglass_forward(t_cu, x.to(dev), 8, train=False)[-1].cpu()
+    torch.cuda.synchronize()
+    # ---- checker 2 (referee): the oracle in fp64 on the CPU ----
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
+    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double())
+    t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in t_sd.items()}
+    with torch.no_grad():
+        t_tmap2 = hourglass_ref.hourglass_forward(t64, x[:2].double(), 8, train=False)[-1]    # eval BN: per-sample
+
+    def err(a, b):
+        return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+    # teacher map: never less accurate than 1.5x the MIOpen fp32 evaluation of the same graph, and close to it
+    e_ours, e_ref = err(ours_tmap[:2], t_tmap2), err(m_tmap[:2], t_tmap2)
+    assert e_ours <= max(1e-4, 1.5 * e_ref), ('teacher map', e_ours, e_ref)
+    assert err(ours_tmap, m_tmap) <= 1e-4 + e_ours + e_ref
+    for i in range(4):
+        e_ours, e_ref = err(ours_maps[i], t_maps[i]), err(m_maps[i], t_maps[i])
+        assert e_ours <= max(1e-4, 1.5 * e_ref), ('student map %d' % i, e_ours, e_ref)
+    assert max(abs(a - b) for a, b in zip((pose, kd, loss), t_loss)) < 1e-5, ((pose, kd, loss), t_loss)
+    # gradients against the fp64 truth: whole-vector relative L2, and per tensor relative to the tensor's own scale
+    def rel_l2(g):
+        num = sum(float(((g[k].double().cpu() - t_grads[k]) ** 2).sum()) for k in t_grads)
+        den = sum(float((t_grads[k] ** 2).sum()) for k in t_grads)
+        return (num / den) ** 0.5
+    r_ours, r_ref = rel_l2(ours_grads), rel_l2(m_grads)
+    assert r_ours <= max(2e-3, 1.5 * r_ref), ('gradient rel. L2 vs fp64', r_ours, r_ref)
+    gmax = max(float(v.abs().max()) for v in t_grads.values())
+    for k, tgrad in t_grads.items():
+        e_o, e_r = err(ours_grads[k], tgrad), err(m_grads[k], tgrad)
+        scale = max(float(tgrad.abs().max()), 1e-4 * gmax)       # (biases in front of a train-mode BN: exact gradient 0)
+        # single tensors carry one realisation of the propagated rounding noise (observed: up to ~9 % of a tensor's scale
+        # for us and for MIOpen alike): this is a gross-error check, the accuracy statement is the whole-vector one above
+        assert e_o <= max(5.0 * e_r, 0.2 * scale), (k, e_o, e_r, scale)
+    print('full size: teacher |ours-fp64| %.2e (miopen %.2e); grads rel-L2 ours %.2e miopen %.2e' % (
+        err(ours_tmap[:2], t_tmap2), err(m_tmap[:2], t_tmap2), r_ours, r_ref))
