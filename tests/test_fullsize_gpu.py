@@ -109,3 +109,69 @@ def test_full_size_fpd_step_matches_the_oracle_run_on_cuda():
         assert e_o <= max(5.0 * e_r, 0.2 * scale), (k, e_o, e_r, scale)
     print('full size: teacher |ours-fp64| %.2e (miopen %.2e); grads rel-L2 ours %.2e miopen %.2e' % (
         err(ours_tmap[:2], t_tmap2), err(m_tmap[:2], t_tmap2), r_ours, r_ref))
+
+
+def _bf16_models(dev):
+    from fpd_amd.lib.models import hourglass
+    J = 16
+    s_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(128, 4, J), 1)
+    t_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(256, 8, J), 2)
+    student = hourglass.get_pose_net(_cfg(128, 4, J, 'bf16'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(256, 8, J, 'bf16'), is_train=False)
+    student.load_state_dict(s_sd, strict=True)
+    teacher.load_state_dict(t_sd, strict=True)
+    return student.to(dev), teacher.to(dev)
+
+
+def test_full_size_code_paths_agree(monkeypatch):
+    """B=32, 256x256: alternative code paths of the same computation must agree -- the fused frozen Bottleneck/head kernels
+    vs the per-convolution graph (bf16 benchmark build; different rounding points: relative L2), and the paired up-/low-branch
+    launches vs one launch per op (fp32 build, see the comment below)."""
+    from fpd_amd import executor as E
+    dev = torch.device('cuda', 0)
+    B, J, H, W = 32, 16, 256, 256
+    x, tg, tw = fpd_ref.synth_batch(100, B, J, (W, H), (W // 4, H // 4))
+    student, teacher = _bf16_models(dev)
+
+    def teacher_map(fuse):
+        monkeypatch.setenv('FPD_FUSE_BNECK', '1' if fuse else '0')
+        g = E.GraphInstance(teacher.device_state(), teacher.cfg_hg, B, H, W, train=False).finalize()
+        kinds = {o.kind for o in g.g.fwd}
+        assert ('head' in kinds and ('bneck' in kinds or 'bneck2' in kinds)) == fuse
+        g.image().copy_(x)
+        g.run('prep'); g.run('fwd')
+        torch.cuda.synchronize()
+        return g.output_view(7).float().cpu()
+    fused, plain = teacher_map(True), teacher_map(False)
+    assert torch.isfinite(fused).all()
+    rel = float((fused - plain).norm() / plain.norm())
+    assert rel < 3e-2, 'fused vs per-conv teacher map: relative L2 %.2e' % rel
+    monkeypatch.setenv('FPD_FUSE_BNECK', '1')
+
+    # paired vs one-launch-per-op student step, checked in the fp32 build: in bf16 the two orderings of the statistics
+    # partials flip a ~1e-4 fraction of roundings by 0.4 %, which this random 4-stack network amplifies ~4000x (the same
+    # factor that turns 1e-7 into 4e-4 in fp32) -- measured 10 % on the last map while identical runs are bit-identical
+    def student_losses(pair):
+        from fpd_amd.lib.models import hourglass
+        monkeypatch.setenv('FPD_PAIR', '1' if pair else '0')
+        s_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(128, 4, J), 1)
+        t_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(256, 8, J), 2)
+        s2 = hourglass.get_pose_net(_cfg(128, 4, J, 'fp32'), is_train=True)
+        t2 = hourglass.get_pose_net(_cfg(256, 8, J, 'fp32'), is_train=False)
+        s2.load_state_dict(s_sd, strict=True)
+        t2.load_state_dict(t_sd, strict=True)
+        s2, t2 = s2.to(dev), t2.to(dev)
+        step = E.FusedFPDStep(s2.device_state(), s2.cfg_hg, t2.device_state(), t2.cfg_hg, B, H, W, alpha=0.5)
+        kinds = {o.kind for o in step.student.g.fwd}
+        assert ('conv2' in kinds) == pair
+        step.set_batch(x, tg, tw)
+        step.teacher_async(x)
+        s = step.student
+        torch.cuda.current_stream().wait_event(step.ev_t[0])
+        s.run('prep'); s.run('fwd'); s.run('mid'); s.run('bwd')
+        torch.cuda.synchronize()
+        return step.losses(), s.output_view(3).float().cpu(), s2.device_state().A.tensor('grad').clone().cpu()
+    (l1, m1, g1), (l0, m0, g0) = student_losses(True), student_losses(False)
+    assert max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(l1, l0)) < 1e-5, (l1, l0)
+    rm, rg = float((m1 - m0).norm() / m0.norm()), float((g1 - g0).norm() / g0.norm())
+    assert rm < 1e-3 and rg < 5e-2, ('paired vs unpaired, fp32: map / gradient relative L2', rm, rg)
