@@ -356,7 +356,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_EW: want = sizeof(fpd_ew_t); break;
         case FPD_OP_LOSS: want = sizeof(fpd_loss_t); break;
         case FPD_OP_ADAM: want = sizeof(fpd_adam_t); break;
-        case FPD_OP_MEMSET: want = sizeof(fpd_memset_t); break;
+        case FPD_OP_MEMSET: case FPD_OP_NOP: want = sizeof(fpd_memset_t); break;
         case FPD_OP_WPREP: case FPD_OP_BNUPD: case FPD_OP_WREDUCE: want = sizeof(fpd_table_t); break;
         default: return fpd_fail(-2, "plan_add: unknown op %d", op);
     }
@@ -377,6 +377,19 @@ int fpd_plan_set_schedule(fpd_plan* p, int32_t op, int32_t lane, const int32_t* 
     s.lane = lane;
     s.waits.assign(wait_ops, wait_ops + n_waits);
     for (int i = 0; i < n_waits; ++i) p->sched[wait_ops[i]].record = true;
+    return 0;
+}
+
+int fpd_plan_mark_event(fpd_plan* p, int32_t op) {
+    FPD_REQUIRE(p && op >= 0 && op < (int)p->ops.size(), "plan_mark_event: bad op index %d", op);
+    p->sched[op].record = true;
+    return 0;
+}
+
+int fpd_plan_wait_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
+    FPD_REQUIRE(p && op >= 0 && op < (int)p->ops.size(), "plan_wait_op: bad op index %d", op);
+    FPD_REQUIRE(p->sched[op].record && p->sched[op].done, "plan_wait_op: op %d has no recorded event (mark it, then run its range)", op);
+    FPD_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->sched[op].done, 0));
     return 0;
 }
 
@@ -401,6 +414,7 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
             FPD_CHECK_HIP(hipMemsetAsync(o.u.mset.ptr, 0, (size_t)o.u.mset.bytes, (hipStream_t)s));
             return 0;
         }
+        case FPD_OP_NOP: return 0;
         case FPD_OP_WPREP:
             return fpd_weight_prep((const fpd_wprep_entry_t*)o.u.table.table, o.u.table.n, o.u.table.max_elems, o.u.table.dtype, s);
         case FPD_OP_BNUPD: return fpd_bn_update_running((const fpd_bnupd_entry_t*)o.u.table.table, o.u.table.n, s);

@@ -43,15 +43,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const fpd_loss_t a) {
         if (p0 + p >= HW) continue;
         const size_t off = ((size_t)b * HW + p0 + p) * J + j;
         const float wgt = a.weight[b * J + j], w2 = wgt * wgt;
+        const float wk = a.weight_kd ? a.weight_kd[b * J + j] : wgt, w2k = wk * wk;
         const float g = s_tg[p * LDJ + j];
         const float t = DT<T>::ld(tch + off);
         for (int s = 0; s < a.S; ++s) {
             const float pv = DT<T>::ld(reinterpret_cast<const T*>(a.out[s]) + off);
             const float dg = pv - g, dt = pv - t;
             pose += w2 * dg * dg;
-            kd += w2 * dt * dt;
+            kd += w2k * dt * dt;
             if (a.dout[s] != nullptr)
-                DT<T>::st(reinterpret_cast<T*>(a.dout[s]) + off, gs * w2 * ((1.f - a.alpha) * dg + a.alpha * dt));
+                DT<T>::st(reinterpret_cast<T*>(a.dout[s]) + off, gs * ((1.f - a.alpha) * w2 * dg + a.alpha * w2k * dt));
         }
     }
     const double dp = wave_sum_d((double)pose), dk = wave_sum_d((double)kd);

@@ -11,10 +11,38 @@ import torch
 
 
 def make_allreduce(dist, group=None):
-    """Returns hook(flat_grad) -> wait() for executor.FusedFPDStep.step(allreduce=...)."""
-    def hook(flat_grad):
-        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        return work.wait            # makes the current stream wait for the collective; no host sync on NCCL/RCCL
+    """Returns hook(flat_grad, buckets=None) -> wait() for executor.FusedFPDStep.student_step(allreduce=...).
+
+    `buckets` = [(begin, end, wait)] (executor.FusedFPDStep.grad_buckets): the flat gradient arena is laid out in the
+    order gradients complete during the backward (graph.ParamTable buckets: last stack first), so each bucket is one
+    contiguous slice and gets its OWN asynchronous all-reduce, issued from a side stream that waits -- on the device --
+    for the plan op after which that slice is final.  The collectives of the early buckets therefore run while the rest
+    of the backward is still executing; only the last bucket's is exposed, and even that overlaps the next step's
+    teacher forward (the student stream waits for the collectives right before Adam)."""
+    comm = {}
+
+    def hook(flat_grad, buckets=None):
+        if not buckets or not flat_grad.is_cuda:
+            work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            return work.wait            # makes the current stream wait for the collective; no host sync on NCCL/RCCL
+        if 's' not in comm:
+            comm['s'] = torch.cuda.Stream(device=flat_grad.device)
+        works = []
+        cur = torch.cuda.current_stream()
+        for lo, hi, wait in buckets:
+            if wait is None:
+                works.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+                continue
+            with torch.cuda.stream(comm['s']):
+                wait(comm['s'])         # RCCL's stream orders itself behind the stream the collective is issued from
+                works.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+        def wait_all():
+            for w in works:
+                w.wait()                # current stream waits for each collective (device-side)
+            return None
+        del cur
+        return wait_all
     return hook
 
 

@@ -65,7 +65,8 @@ class Lowering:
         self.A, self.dtype = arenas, dtype
         self.keep = []          # device tables that must outlive the plan
         self.use_partials = False
-        self.partials, self.partial_elems = [], 0
+        self.partials, self.partial_elems = {}, 0      # id(IR wgrad op) -> slab record
+        self.reduces = []                              # (IR wreduce op, its TableT) filled in by finish_partials()
 
     def bn(self, bn):
         s = R.BnT()
@@ -129,31 +130,45 @@ class Lowering:
             if n > 0:
                 numel = op.dw.numel
                 stride = (numel + s.K + 63) // 64 * 64          # weight slab + bias partials
-                self.partials.append([s, op.dw, numel, stride, n, self.partial_elems, op.dbias])
+                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias]
                 self.partial_elems += n * stride
         return R.OP_WGRAD, s
 
+    def wreduce(self, op):
+        """Second stage of the weight-gradient reduction for the convolutions of ONE gradient bucket (op.wgrads, all
+        lowered before this op): dw += sum of slabs, one launch.  The table is filled in by finish_partials()."""
+        if not any(id(w) in self.partials for w in op.wgrads):
+            return R.OP_NOP, R.MemsetT()
+        t = R.TableT()
+        self.reduces.append((op, t))
+        return R.OP_WREDUCE, t
+
     def finish_partials(self):
-        """Allocate the slab workspace, patch the recorded wgrad structs, return the reduce op (or None)."""
+        """Allocate the slab workspace, patch the recorded wgrad structs and fill the reduce tables (call after every
+        backward op has been lowered and BEFORE the structs are copied into the plan)."""
         if not self.partials:
-            return None
+            return
         ws = torch.empty(self.partial_elems, dtype=torch.float32, device=self.A.device)
         self.keep.append(ws)
-        ents, mx = [], 0
-        for s, dw, numel, stride, n, off, dbias in self.partials:
+        for s, dw, numel, stride, n, off, dbias in self.partials.values():
             s.partial = ws.data_ptr() + 4 * off
             s.partial_stride = stride
-            e = R.WreduceEntryT()
-            e.partial, e.dw, e.n, e.stride, e.count = s.partial, self.A.ptr(dw), numel, stride, n
-            ents.append(e)
-            if dbias is not None:
+        for op, t in self.reduces:
+            ents, mx = [], 0
+            for w in op.wgrads:
+                rec = self.partials.get(id(w))
+                if rec is None:
+                    continue
+                s, dw, numel, stride, n, off, dbias = rec
                 e = R.WreduceEntryT()
-                e.partial, e.dw, e.n, e.stride, e.count = s.partial + 4 * numel, self.A.ptr(dbias), s.K, stride, n
+                e.partial, e.dw, e.n, e.stride, e.count = s.partial, self.A.ptr(dw), numel, stride, n
                 ents.append(e)
-            mx = max(mx, numel)
-        t = R.TableT()
-        t.table, t.n, t.dtype, t.max_elems = self._table(ents, R.WreduceEntryT), len(ents), self.dtype, mx
-        return R.OP_WREDUCE, t
+                if dbias is not None:
+                    e = R.WreduceEntryT()
+                    e.partial, e.dw, e.n, e.stride, e.count = s.partial + 4 * numel, self.A.ptr(dbias), s.K, stride, n
+                    ents.append(e)
+                mx = max(mx, numel)
+            t.table, t.n, t.dtype, t.max_elems = self._table(ents, R.WreduceEntryT), len(ents), self.dtype, mx
 
     def stem(self, op):
         s = R.StemT()
@@ -233,6 +248,10 @@ class Lowering:
             return R.OP_HEAD_FOLD, self.head(op.target)[1]
         if op.kind == 'bneck_fold':
             return R.OP_BNECK_FOLD, self.bneck(op.target)[1]
+        if op.kind == 'wreduce':
+            return self.wreduce(op)
+        if op.kind == 'grad_ready':
+            return R.OP_NOP, R.MemsetT()
         return {'conv': self.conv, 'bneck': self.bneck, 'wgrad': self.wgrad, 'stem_fwd': self.stem, 'stem_wgrad': self.stem, 'ew': self.ew,
                 'bnupd': self.bnupd}[op.kind](op)
 
@@ -299,12 +318,14 @@ class GraphInstance:
         self.act_elems = act
         self.A.alloc('act', act)
         self.A.alloc('stats', g.stats_size)
-        self.A.alloc('fold', g.fold_size)
-        if self._wlp_owner is not None:            # same ParamTable -> same layout of the working-weight arena
-            assert self._wlp_owner.g.wlp_size == g.wlp_size and not self.train
-            self.A.t['wlp'] = self._wlp_owner.A.t['wlp']
+        if self._wlp_owner is not None:            # same ParamTable / same graph -> same layout of the working-weight arena
+            o = self._wlp_owner                    # and of the folded BN tables, both written by the owner's 'prep' phase
+            assert o.g.wlp_size == g.wlp_size and o.g.fold_size == g.fold_size and not self.train
+            self.A.t['wlp'] = o.A.t['wlp']
+            self.A.t['fold'] = o.A.t['fold']
         else:
             self.A.alloc('wlp', g.wlp_size)
+            self.A.alloc('fold', g.fold_size)
         if self._image_ext is not None:
             self.A.t['image'] = self._image_ext
         else:
@@ -343,13 +364,15 @@ class GraphInstance:
             self.low.use_partials = True
             bwd_ir = [op for op in g.bwd if op.kind != 'seed']
             lowered = [self.low.op(op) for op in bwd_ir]
-            red = self.low.finish_partials()          # patches the wgrad structs with their slab pointers
-            for code, st in lowered:
-                p.add(code, st)
-            if red is not None:
-                p.add(*red)                           # dw += sum of slabs, all convolutions in one launch
+            self.low.finish_partials()                # patches the wgrad structs / fills the per-bucket reduce tables
+            self.bucket_ops = {}                      # gradient bucket -> plan op after which its grad slice is final
+            for ir, (code, st) in zip(bwd_ir, lowered):
+                k = p.add(code, st)
+                if ir.kind == 'grad_ready':
+                    self.bucket_ops[ir.bucket] = k
+                    p.mark_event(k)
             self.rng['bwd'] = (b, len(p))
-            self._schedule('bwd', [None] + bwd_ir + ([None] if red is not None else []))
+            self._schedule('bwd', [None] + bwd_ir)
         self._finalized = True
         return self
 
@@ -402,8 +425,12 @@ class FusedFPDStep:
     No host synchronisation inside; losses are read back only when asked for."""
 
     def __init__(self, student_state, student_cfg, teacher_state, teacher_cfg, batch, height, width, alpha,
-                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1, adam=None, teacher_chunks=None):
+                 lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, world_size=1, adam=None, teacher_chunks=None,
+                 use_target_weight=(True, True)):
         dev = student_state.device
+        # JointsMSELoss(use_target_weight) of the pose / distillation criterion (tools/fpd_train.py:145-147,177-179):
+        # False = that term ignores the loader's target_weight (loss.py:30-37), i.e. a weight buffer of ones
+        self.use_w = (bool(use_target_weight[0]), bool(use_target_weight[1]))
         self.dtype = student_state.dtype
         self.alpha, self.world_size = alpha, world_size
         self.B, self.J = batch, student_cfg['J']
@@ -441,6 +468,10 @@ class FusedFPDStep:
         A = self.student.A
         A.alloc('target', self.B * self.J * self.hh * self.hw)
         A.alloc('weight', self.B * self.J)
+        if self.use_w[0] != self.use_w[1]:
+            A.t['weight_kd'] = torch.ones(self.B * self.J, dtype=torch.float32, device=dev)
+        if not self.use_w[0]:
+            A.tensor('weight').fill_(1.0)
         A.alloc('losses', 4)
         self.student.mid_ops = [G.Op('loss', extra_in=list(g.outputs), extra_out=list(g.out_grads))]
         self.student.mid_native = [lambda plan: self._add_loss(plan, 0)]
@@ -482,7 +513,7 @@ class FusedFPDStep:
             from .lib.core.evaluate import DeviceAccuracy
             g, A = self.student.g, self.student.A
             self.metric = DeviceAccuracy(self.B, self.J, self.hh, self.hw, self.dtype, self.student.state.device).bind(
-                A.ptr(g.outputs[-1].buf), A.tensor('target').data_ptr())
+                A.ptr(g.outputs[-1].buf), A.tensor('target').data_ptr(), A.tensor('losses').data_ptr())
         return self.metric
 
     def _add_loss(self, plan, slot):
@@ -499,6 +530,7 @@ class FusedFPDStep:
         else:                                   # plain (non-KD) training: alpha must be 0, kd term reads the student map
             s.teacher = A.ptr(g.outputs[-1].buf)
         s.target, s.weight = A.tensor('target').data_ptr(), A.tensor('weight').data_ptr()
+        s.weight_kd = A.tensor('weight_kd').data_ptr() if 'weight_kd' in A.t else None
         s.losses = A.tensor('losses').data_ptr()
         s.grad_scale = 1.0 / self.world_size
         plan.add(R.OP_LOSS, s)
@@ -508,7 +540,10 @@ class FusedFPDStep:
         """Copy one loader batch (any device) into the student's fixed HBM buffers (async on the current stream)."""
         self.student.image().copy_(inp, non_blocking=True)
         self.student.A.tensor('target').view(target.shape).copy_(target, non_blocking=True)
-        self.student.A.tensor('weight').view(target_weight.shape).copy_(target_weight, non_blocking=True)
+        if self.use_w[0]:
+            self.student.A.tensor('weight').view(target_weight.shape).copy_(target_weight, non_blocking=True)
+        elif self.use_w[1]:
+            self.student.A.tensor('weight_kd').view(target_weight.shape).copy_(target_weight, non_blocking=True)
         self._last_inp = inp
 
     # ---- one iteration = teacher_async(batch) + student_step(batch) ----
@@ -557,10 +592,28 @@ class FusedFPDStep:
             self.metric.enqueue()
         s.run('bwd')
         if allreduce is not None:
-            self._dist_work = allreduce(self.student.state.A.tensor('grad'))
+            self._dist_work = allreduce(self.student.state.A.tensor('grad'), self.grad_buckets())
         else:
             s.run('adam')
         self._k_s += 1
+
+    def grad_buckets(self):
+        """[(first element, end element, wait)] of the flat gradient arena in completion order: `wait(stream)` makes a
+        torch stream wait (on the device, no host sync) for the point of the just-enqueued backward where that slice is
+        final, so its all-reduce can be issued on another stream while the rest of the backward runs.  One bucket (the
+        whole arena, no wait needed: it is issued behind the backward) when the phases are replayed as hipGraphs."""
+        s = self.student
+        n = self.n_param
+        if s.graphs.get('bwd') is not None or not getattr(s, 'bucket_ops', None):
+            return [(0, n, None)]
+        table = s.state.table
+        out = []
+        for b, (lo, hi) in enumerate(table.buckets):
+            op = s.bucket_ops.get(b)
+            if op is None or hi <= lo:
+                continue
+            out.append((lo, hi, (lambda stream, op=op: s.plan.wait_op(op, C.c_void_p(stream.cuda_stream)))))
+        return out
 
     def enable_graphs(self):
         """Replay every phase as a hipGraph from now on (call after at least one eager step)."""

@@ -108,6 +108,10 @@ class Op:
         elif k == 'wgrad':
             rd = [b(self.x), b(self.dy)] + bn_bufs(self.bn)
             wr = [self.dw, self.dbias]
+        elif k == 'wreduce':                   # sums the slabs of its weight gradients into dw / dbias
+            rd, wr = list(self.bufs), list(self.bufs)
+        elif k == 'grad_ready':                # marker: every gradient of one bucket is final once this op has run
+            rd, wr = [self.region], []
         elif k == 'stem_fwd':
             rd, wr = [self.image, self.w, self.bias], [b(self.y), self.out_stats]
         elif k == 'stem_wgrad':
@@ -144,12 +148,19 @@ class ParamTable:
     K,R,S,C = the OIHW tensor in channels-last memory order; biases; BN affine) in state_dict order;
     'rstat': BN running mean/var; 'nbt': num_batches_tracked."""
 
-    def __init__(self, keys):
+    def __init__(self, keys, bucket_of=None):
+        """`bucket_of(key) -> int` (optional) groups the trainable tensors into gradient buckets: bucket 0 is the one
+        whose gradients are complete FIRST in a backward pass.  The 'param' (and with it the 'grad') arena is laid out
+        bucket by bucket, so that each bucket is ONE contiguous slice -- one RCCL all-reduce issued while the rest of
+        the backward still runs.  state_dict order (self.keys / self.entries) is unaffected."""
         self.keys = list(keys)                     # [(key, logical_shape)]
         self.entries = OrderedDict()               # key -> Buf
         self.logical = dict(self.keys)
         self.sizes = {'param': 0, 'rstat': 0, 'nbt': 0}
-        for k, shp in self.keys:
+        self.bucket = {k: (bucket_of(k) if bucket_of else 0) for k, _ in self.keys}
+        placed = {}
+        self.buckets = []                          # [(first element, end element)] of the param/grad arena per bucket
+        for k, shp in sorted(self.keys, key=lambda ks: self.bucket[ks[0]]):   # stable: key order within a bucket
             if k.endswith('num_batches_tracked'):
                 arena = 'nbt'
             elif k.endswith('running_mean') or k.endswith('running_var'):
@@ -161,10 +172,18 @@ class ParamTable:
                 n *= s
             phys = (shp[0], shp[2], shp[3], shp[1]) if len(shp) == 4 else tuple(shp)
             off = self.sizes[arena]
-            self.entries[k] = Buf(arena, off, phys, k)
+            placed[k] = Buf(arena, off, phys, k)
             # keep every tensor 16-byte aligned in its arena
             step = 4 if arena != 'nbt' else 2
             self.sizes[arena] = off + (n + step - 1) // step * step
+            if arena == 'param':
+                b = self.bucket[k]
+                while len(self.buckets) <= b:
+                    self.buckets.append([off, off])
+                self.buckets[b][1] = self.sizes[arena]
+        for k, _ in self.keys:
+            self.entries[k] = placed[k]
+        self.buckets = [tuple(b) for b in self.buckets]
 
     def __getitem__(self, k):
         return self.entries[k]
@@ -178,6 +197,22 @@ class ParamTable:
 
     def trainable_keys(self):
         return [k for k, b in self.entries.items() if b.arena == 'param']
+
+    def grad_bucket(self, b):
+        """The gradient arena slice of bucket b as a Buf (dependency analysis of the 'grad_ready' ops)."""
+        lo, hi = self.buckets[b]
+        return Buf('grad', lo, (hi - lo,), 'grad:bucket%d' % b)
+
+
+def hourglass_bucket_of(num_stacks):
+    """Gradient buckets of a stacked hourglass: one per stack, in the order their gradients complete in a backward pass
+    (last stack first); the stem (conv1, bn1, layer1-3) finishes last and joins stack 0's bucket."""
+    def f(key):
+        p = key.split('.')
+        if p[0] in ('hg', 'res', 'fc', 'score', 'fc_', 'score_'):
+            return num_stacks - 1 - int(p[1])
+        return num_stacks - 1
+    return f
 
 
 # ------------------------------------------------------------------------------------------------
@@ -571,8 +606,17 @@ class HourglassGraph:
         # liveness marker: the output gradients are written (by the loss kernel or by autograd's seeds) BEFORE the
         # first backward op runs, so they must be placed here, not at their first use deep inside the backward list
         self.bwd.append(Op('seed', extra_in=list(self.outputs), extra_out=list(self.out_grads)))
+        self._cur_bucket, self._wg_bucket = None, []
         for op in reversed(self.fwd):
             self._lane = op.lane                 # gradients flow on the lane of the forward op they belong to
+            bk = self._op_bucket(op)
+            if bk is not None and bk != self._cur_bucket:
+                if self._cur_bucket is not None:
+                    assert bk > self._cur_bucket, 'gradient buckets must complete in increasing order'
+                    self._lane = 0
+                    self._close_bucket(self._cur_bucket)
+                    self._lane = op.lane
+                self._cur_bucket = bk
             if len(self._wg_pending) >= self.wgrad_batch and op.lane == 0:
                 self._flush_wgrads()
             if op.kind == 'conv':
@@ -596,14 +640,39 @@ class HourglassGraph:
             elif op.kind == 'ew':
                 self._ew_backward(op)
         self._lane = 0
-        self._flush_wgrads()
+        self._close_bucket(self._cur_bucket if self._cur_bucket is not None else 0)
         assert not self._bn_pending, 'unfinished BN backward: %r' % list(self._bn_pending)
+
+    def _op_bucket(self, op):
+        """Gradient bucket of the parameters a forward op owns (None: the op has no parameters)."""
+        if op.kind in ('conv2', 'bneck2', 'ew2'):
+            return self._op_bucket(op.a)
+        key = getattr(op, 'wkey', None)
+        if key is None and op.kind == 'stem_fwd':
+            key = 'conv1.weight'
+        if key is None and getattr(op, 'bn', None) is not None:
+            key = op.bn.name + '.weight'
+        return None if key is None else self.p.bucket[key]
+
+    def _close_bucket(self, b):
+        """All forward ops owning parameters of bucket b have been differentiated: issue the remaining weight gradients,
+        reduce the bucket's slabs and mark the point where its slice of the gradient arena is final (the data-parallel
+        all-reduce of that slice can start there, overlapping the rest of the backward)."""
+        self._flush_wgrads()
+        lane = 1 + self.depth
+        if self._wg_bucket:
+            bufs = [x for w in self._wg_bucket for x in (w.dw, w.dbias) if x is not None]
+            self.bwd.append(Op('wreduce', bucket=b, wgrads=list(self._wg_bucket), bufs=bufs, lane=lane))
+        self._wg_bucket = []
+        self.bwd.append(Op('grad_ready', bucket=b, region=self.p.grad_bucket(b), lane=lane))
 
     def _flush_wgrads(self):
         """Weight gradients are leaves: they are collected and issued in batches on their own lane, newest first, so
         that the batch's first kernel carries the one cross-lane wait that covers the whole batch."""
         for w in reversed(self._wg_pending):
             self.bwd.append(w)
+            if w.kind == 'wgrad':
+                self._wg_bucket.append(w)
         self._wg_pending = []
 
     def _emit_dgrad(self, op):

@@ -2,15 +2,22 @@
 the fused MI355X step (executor.FusedFPDStep): per batch the frozen-teacher forward, the student forward/backward, the
 pose + distillation JointsMSELoss of every stack, the data-parallel gradient exchange and Adam run as recorded HIP
 plans with no host synchronisation; the teacher runs one batch ahead on its own stream (it does not depend on the
-student weights); losses / accuracy are read back only when a log line is due (PRINT_FREQ)."""
+student weights).  Like the reference (function.py:150-155) EVERY iteration feeds the loss and accuracy meters: the
+device appends {avg_acc, cnt, pose, kd} of each iteration to a ring (csrc/pck.hip) that is drained -- the only host
+synchronisation of the loop -- when a log line is due (PRINT_FREQ) and at the end of the epoch.
+
+Not silently substituted: the fused step implements Adam (lib.utils.utils.FusedAdam) and JointsMSELoss criteria; any
+other optimizer / criterion object raises instead of being ignored."""
 import logging
 import time
 
 import torch
 
 from ... import executor as E
+from ... import runtime as R
 from ..utils.utils import FusedAdam
-from .evaluate import accuracy
+from .evaluate import accuracy  # noqa: F401  (re-exported like the reference's core.function namespace)
+from .loss import JointsMSELoss
 
 logger = logging.getLogger(__name__)
 
@@ -36,76 +43,105 @@ def _unwrap(m):
     return m.module if hasattr(m, 'module') else m
 
 
-def fused_step_for(model, tmodel, optimizer, batch_shape, alpha, world_size=1):
-    """One FusedFPDStep per (student, teacher, batch shape); shares Adam state with a FusedAdam optimizer."""
-    s, t = _unwrap(model), _unwrap(tmodel)
-    key = (id(s), id(t), tuple(batch_shape), float(alpha), world_size)
+def _check_supported(optimizer, pose_criterion, kd_pose_criterion):
+    """The fused step runs ITS Adam and ITS JointsMSELoss: refuse objects it would otherwise silently ignore."""
+    if not isinstance(optimizer, FusedAdam):
+        raise R.FpdError('fpd_train: the fused MI355X step implements Adam only (utils.get_optimizer with TRAIN.OPTIMIZER '
+                         "'adam' -> FusedAdam); got %s -- its update rule and state would be ignored" % type(optimizer).__name__)
+    for name, c in (('pose_criterion', pose_criterion), ('kd_pose_criterion', kd_pose_criterion)):
+        if not isinstance(c, JointsMSELoss):
+            raise R.FpdError('fpd_train: %s must be a core.loss.JointsMSELoss (the fused loss kernel evaluates exactly that '
+                             'criterion), got %s' % (name, type(c).__name__))
+    return bool(pose_criterion.use_target_weight), bool(kd_pose_criterion.use_target_weight)
+
+
+def fused_step_for(model, tmodel, optimizer, batch_shape, alpha, world_size=1, use_target_weight=(True, True)):
+    """One FusedFPDStep per (student, teacher, batch shape); shares Adam state with the FusedAdam optimizer.
+    tmodel None = plain (non-distillation) training: no teacher graph, alpha must be 0."""
+    s, t = _unwrap(model), (_unwrap(tmodel) if tmodel is not None else None)
+    key = (id(s), id(t), id(optimizer), tuple(batch_shape), float(alpha), world_size, tuple(use_target_weight))
     if key not in _STEPS:
         n, _, h, w = batch_shape
-        step = E.FusedFPDStep(s.device_state(), s.cfg_hg, t.device_state(), t.cfg_hg, n, h, w, alpha,
+        assert t is not None or alpha == 0.0
+        step = E.FusedFPDStep(s.device_state(), s.cfg_hg, t.device_state() if t is not None else None,
+                              t.cfg_hg if t is not None else None, n, h, w, alpha,
                               lr=float(optimizer.param_groups[0]['lr']), world_size=world_size,
-                              adam=optimizer if isinstance(optimizer, FusedAdam) else None)
+                              adam=optimizer, use_target_weight=use_target_weight)
         _STEPS[key] = step
     return _STEPS[key]
 
 
-def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_criterion, optimizer, epoch,
-              output_dir, tb_log_dir, writer_dict, allreduce=None, world_size=1):
+def _run_epoch(config, train_loader, model, tmodel, use_w, optimizer, epoch, writer_dict, allreduce, world_size, alpha):
+    """The loop shared by fpd_train (function.py:99-187) and train (function.py:28-96; tmodel None, alpha 0)."""
+    kd_mode = tmodel is not None
     batch_time, data_time = AverageMeter(), AverageMeter()
     losses, pose_losses, kd_pose_losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
-    alpha = config.KD.ALPHA
     model.train()          # function.py:110-111
-    tmodel.eval()
-    step = None
+    if kd_mode:
+        tmodel.eval()
+    step = metric = None
     end = time.time()
     it = iter(train_loader)
     nxt = next(it, None)
     i = -1
+    n_img = 0
+
+    def drain():
+        """Feed the meters with every iteration since the last drain (function.py:150-155); synchronises."""
+        for avg_acc, cnt, pose, kd in metric.drain(full=True):
+            pose_losses.update(pose, n_img); kd_pose_losses.update(kd, n_img)
+            losses.update((1 - alpha) * pose + alpha * kd, n_img)
+            acc.update(avg_acc, cnt)
+
     while nxt is not None:
         i += 1
         inp, target, target_weight, meta = nxt
         data_time.update(time.time() - end)
         if step is None or tuple(inp.shape) != tuple(step.student.image().shape):
-            if step is not None:
+            if step is not None:                       # batch shape changed (last, smaller batch): finish the old step
                 step.flush()
-            step = fused_step_for(model, tmodel, optimizer, inp.shape, alpha, world_size)
-            metric = step.enable_metric()              # PCK of every iteration, accumulated on the device
+                drain()
+            step = fused_step_for(model, tmodel, optimizer, inp.shape, alpha, world_size, use_w)
+            metric = step.enable_metric()              # PCK + losses of every iteration, logged on the device
             metric.drain()
+            n_img = inp.size(0)
             step.teacher_async(inp)                    # pipeline prologue: teacher forward of the first batch
-        if isinstance(optimizer, FusedAdam):
-            optimizer.sync_lr()
-        else:
-            step.set_lr(float(optimizer.param_groups[0]['lr']))
+        optimizer.sync_lr()
         step.set_batch(inp, target, target_weight)
         nxt = next(it, None)
         if nxt is not None and tuple(nxt[0].shape) == tuple(inp.shape):
             step.teacher_async(nxt[0])                 # teacher runs one batch ahead, overlapping this student step
-        elif nxt is not None:
-            pass                                       # shape change: the new step object primes itself above
         step.student_step(allreduce)
         if i % config.PRINT_FREQ == 0:
-            pose, kd, loss = step.losses()                    # the only host sync of the loop
-            n = inp.size(0)
-            pose_losses.update(pose, n); kd_pose_losses.update(kd, n); losses.update(loss, n)
-            for avg_acc, cnt in metric.drain():               # one entry per iteration since the last log line,
-                acc.update(avg_acc, cnt)                      # exactly what function.py:154-155 feeds its meter
+            drain()                                    # the only host sync of the loop
             batch_time.update(time.time() - end)
-            msg = 'Epoch: [{0}][{1}/{2}]\t' \
-                  'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
-                  'Speed {speed:.1f} samples/s\t' \
-                  'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
-                  'POSE_Loss {pose_loss.val:.5f} ({pose_loss.avg:.5f})\t' \
-                  'KD_POSE_Loss {kd_pose_loss.val:.5f} ({kd_pose_loss.avg:.5f})\t' \
-                  'Loss {loss.val:.5f} ({loss.avg:.5f})\t' \
-                  'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
-                      epoch, i, len(train_loader), batch_time=batch_time,
-                      speed=inp.size(0) * world_size / max(batch_time.val, 1e-9), data_time=data_time, pose_loss=pose_losses,
-                      kd_pose_loss=kd_pose_losses, loss=losses, acc=acc)
+            speed = inp.size(0) * world_size / max(batch_time.val, 1e-9)
+            if kd_mode:
+                msg = 'Epoch: [{0}][{1}/{2}]\t' \
+                      'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
+                      'Speed {speed:.1f} samples/s\t' \
+                      'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
+                      'POSE_Loss {pose_loss.val:.5f} ({pose_loss.avg:.5f})\t' \
+                      'KD_POSE_Loss {kd_pose_loss.val:.5f} ({kd_pose_loss.avg:.5f})\t' \
+                      'Loss {loss.val:.5f} ({loss.avg:.5f})\t' \
+                      'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
+                          epoch, i, len(train_loader), batch_time=batch_time, speed=speed, data_time=data_time,
+                          pose_loss=pose_losses, kd_pose_loss=kd_pose_losses, loss=losses, acc=acc)
+            else:
+                msg = 'Epoch: [{0}][{1}/{2}]\t' \
+                      'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
+                      'Speed {speed:.1f} samples/s\t' \
+                      'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
+                      'Loss {loss.val:.5f} ({loss.avg:.5f})\t' \
+                      'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
+                          epoch, i, len(train_loader), batch_time=batch_time, speed=speed, data_time=data_time,
+                          loss=losses, acc=acc)
             logger.info(msg)
             if writer_dict is not None and writer_dict.get('writer') is not None:
                 w, gs = writer_dict['writer'], writer_dict['train_global_steps']
-                w.add_scalar('train_pose_loss', pose_losses.val, gs)
-                w.add_scalar('train_kd_pose_loss', kd_pose_losses.val, gs)
+                if kd_mode:
+                    w.add_scalar('train_pose_loss', pose_losses.val, gs)
+                    w.add_scalar('train_kd_pose_loss', kd_pose_losses.val, gs)
                 w.add_scalar('train_loss', losses.val, gs)
                 w.add_scalar('train_acc', acc.val, gs)
                 writer_dict['train_global_steps'] = gs + 1
@@ -114,6 +150,22 @@ def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_crite
         end = time.time()
     if step is not None:
         step.flush()
-        for avg_acc, cnt in metric.drain():
-            acc.update(avg_acc, cnt)
-    return losses.avg
+        drain()
+    return {'loss': losses.avg, 'pose_loss': pose_losses.avg, 'kd_pose_loss': kd_pose_losses.avg, 'acc': acc.avg,
+            'iterations': losses.count // max(n_img, 1) if n_img else 0}
+
+
+def fpd_train(config, train_loader, model, tmodel, pose_criterion, kd_pose_criterion, optimizer, epoch,
+              output_dir, tb_log_dir, writer_dict, allreduce=None, world_size=1):
+    """function.py:99-187 (same positional signature; allreduce / world_size are the data-parallel extras).  Returns the
+    epoch's average loss (the reference returns None)."""
+    use_w = _check_supported(optimizer, pose_criterion, kd_pose_criterion)
+    return _run_epoch(config, train_loader, model, tmodel, use_w, optimizer, epoch, writer_dict, allreduce, world_size,
+                      float(config.KD.ALPHA))['loss']
+
+
+def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, tb_log_dir, writer_dict,
+          allreduce=None, world_size=1):
+    """function.py:28-96: plain (non-distillation) training = the same fused step without a teacher graph (alpha 0)."""
+    use_w = _check_supported(optimizer, criterion, criterion)
+    return _run_epoch(config, train_loader, model, None, use_w, optimizer, epoch, writer_dict, allreduce, world_size, 0.0)['loss']

@@ -119,7 +119,7 @@ class HourglassNet(nn.Module):
         dt = str(kwargs.get('dtype', cfg_dt))
         self.fpd_dtype = R.BF16 if dt in ('bf16', 'bfloat16') else R.F32
         keys = hourglass_keys(self.cfg_hg['F'], self.cfg_hg['S'], self.cfg_hg['J'], self.cfg_hg['num_blocks'])
-        self.table = G.ParamTable(keys)
+        self.table = G.ParamTable(keys, bucket_of=G.hourglass_bucket_of(self.cfg_hg['S']))
         self._flat = {n: torch.zeros(max(self.table.sizes[n], 4), dtype=torch.int64 if n == 'nbt' else torch.float32)
                       for n in ('param', 'rstat', 'nbt')}
         self._flat_grad = None

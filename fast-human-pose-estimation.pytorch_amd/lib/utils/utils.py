@@ -14,15 +14,15 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.model = model.module if hasattr(model, 'module') else model
         super().__init__(list(self.model.parameters()), dict(lr=lr, betas=betas, eps=eps))
-        st = self.model.device_state()
-        flat = st.A.tensor('param')
-        self.m = torch.zeros_like(flat)
+        flat = self.model._flat['param']         # the flat fp32 arena every parameter is a view of (create the optimizer
+        self.m = torch.zeros_like(flat)          # AFTER .to(device), like any torch optimizer)
         self.v = torch.zeros_like(flat)
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=flat.device)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=flat.device)
         self._lr_host = lr
 
     def sync_lr(self):
+        """param_groups[0]['lr'] (what LR schedules write) -> the device scalar the Adam kernel reads."""
         lr = float(self.param_groups[0]['lr'])
         if lr != self._lr_host:
             self.lr_dev.fill_(lr)
@@ -50,12 +50,63 @@ class FusedAdam(torch.optim.Optimizer):
         st = self.model.device_state()
         st.A.tensor('grad').zero_()
 
+    # ---- checkpoint interop: the state dict has torch.optim.Adam's layout (per-parameter exp_avg / exp_avg_sq in the
+    #      reference's OIHW shapes), so `checkpoint['optimizer']` written here loads into the reference's Adam and a
+    #      reference checkpoint resumes here (tools/fpd_train.py:224-234, AUTO_RESUME) ----
+    def _views(self, flat):
+        m = self.model
+        out = []
+        for key in m.table.trainable_keys():
+            b = m.table[key]
+            v = flat[b.off:b.off + b.numel].view(b.shape)
+            out.append(v.permute(0, 3, 1, 2) if len(b.shape) == 4 else v)
+        return out
+
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'step': self.step_dev, 'param_groups': self.param_groups}
+        step = self.step_dev.to(torch.float32).reshape(())
+        state = {}
+        if int(self.step_dev.item()) > 0:
+            for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+                state[i] = {'step': step.clone(), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+        g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        g.setdefault('weight_decay', 0)
+        g.setdefault('amsgrad', False)
+        g['params'] = list(range(len(self.param_groups[0]['params'])))
+        return {'state': state, 'param_groups': [g]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_dev.copy_(sd['step'])
-        self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+        if 'm' in sd and 'v' in sd:                      # round-1 flat layout
+            self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_dev.copy_(sd['step'])
+        else:
+            st = sd.get('state', {})
+            mv, vv = self._views(self.m), self._views(self.v)
+            if len(st) not in (0, len(mv)):
+                raise ValueError('optimizer state has %d parameter entries, the model has %d' % (len(st), len(mv)))
+            self.m.zero_(); self.v.zero_(); self.step_dev.zero_()
+            ids = sd['param_groups'][0]['params']
+            for dst_m, dst_v, pid in zip(mv, vv, ids):
+                e = st.get(pid)
+                if e is None:
+                    continue
+                dst_m.copy_(e['exp_avg']); dst_v.copy_(e['exp_avg_sq'])
+                self.step_dev.fill_(int(float(e['step'])))
+        g = sd['param_groups'][0]
+        for k in ('lr', 'betas', 'eps', 'initial_lr'):   # initial_lr: what torch's LR schedulers resume from
+            if k in g:
+                self.param_groups[0][k] = tuple(g[k]) if k == 'betas' else g[k]
+        self.param_groups[0].setdefault('initial_lr', self.param_groups[0]['lr'])
+        self._lr_host = None
+        self.sync_lr()
+
+
+def multistep_lr(base_lr, milestones, gamma, epoch):
+    """Learning rate the reference trains epoch `epoch` with (tools/fpd_train.py:236-239,253: MultiStepLR built with
+    last_epoch = -1 and stepped at the START of every epoch, so epoch e runs at the scheduler's value for e + 1, i.e.
+    a milestone m takes effect in epoch m - 1).  Closed form, so a resumed run continues exactly where an
+    uninterrupted one would be (torch's chainable scheduler form re-applies a milestone that falls on the resume epoch
+    when it is handed an already-decayed lr; the reference under torch 1.0 additionally skips one epoch on resume --
+    neither artefact is reproduced)."""
+    return base_lr * gamma ** sum(1 for m in milestones if m <= epoch + 1)
 
 
 def get_optimizer(cfg, model):
@@ -63,6 +114,7 @@ def get_optimizer(cfg, model):
     if cfg.TRAIN.OPTIMIZER == 'adam':
         return FusedAdam(model, lr=cfg.TRAIN.LR)
     if cfg.TRAIN.OPTIMIZER == 'sgd':
+        # usable through the module API (autograd + .grad views); core.function.fpd_train refuses it (fused Adam only)
         return torch.optim.SGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM,
                                weight_decay=cfg.TRAIN.WD, nesterov=cfg.TRAIN.NESTEROV)
     raise ValueError('unknown optimizer %r' % cfg.TRAIN.OPTIMIZER)

@@ -16,7 +16,8 @@ BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
  EW_ADD) = range(8)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
- OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK, OP_HEAD, OP_HEAD_FOLD) = range(19)
+ OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK, OP_HEAD, OP_HEAD_FOLD,
+ OP_NOP) = range(20)
 MAX_STACKS = 8
 MAXC = 512
 
@@ -80,14 +81,14 @@ class HeadT(C.Structure):
 
 class PckT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('dtype', _i32), ('log_slots', _i32), ('thr', C.c_float),
-                ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp)]
+                ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp), ('losses', _vp)]
 
 
 class LossT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('S', _i32), ('dtype', _i32),
                 ('target_nchw', _i32), ('alpha', _f32), ('out', _vp * MAX_STACKS), ('dout', _vp * MAX_STACKS),
                 ('teacher', _vp), ('target', _vp), ('weight', _vp), ('losses', _vp), ('grad_scale', _f32),
-                ('_pad', _i32)]
+                ('_pad', _i32), ('weight_kd', _vp)]
 
 
 class AdamT(C.Structure):
@@ -151,6 +152,8 @@ SYMBOLS = {
     'fpd_plan_add': (C.c_int, [_vp, _i32, _vp, _i64]),
     'fpd_plan_size': (C.c_int, [_vp]),
     'fpd_plan_set_schedule': (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_int32), _i32]),
+    'fpd_plan_mark_event': (C.c_int, [_vp, _i32]),
+    'fpd_plan_wait_op': (C.c_int, [_vp, _i32, _vp]),
     'fpd_plan_run': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpd_plan_capture': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpd_plan_replay': (C.c_int, [_vp, _i32, _vp]),
@@ -234,6 +237,13 @@ class Plan:
     def set_schedule(self, op, lane, waits=()):
         arr = (C.c_int32 * max(len(waits), 1))(*waits)
         check(self._l.fpd_plan_set_schedule(self._p, op, lane, arr, len(waits)), 'fpd_plan_set_schedule')
+
+    def mark_event(self, op):
+        check(self._l.fpd_plan_mark_event(self._p, op), 'fpd_plan_mark_event')
+
+    def wait_op(self, op, stream):
+        """Make `stream` (a raw hipStream_t as c_void_p) wait for the last run of plan op `op`."""
+        check(self._l.fpd_plan_wait_op(self._p, op, stream), 'fpd_plan_wait_op')
 
     def run(self, begin, end, stream=None):
         check(self._l.fpd_plan_run(self._p, begin, end, stream if stream is not None else current_stream()),

@@ -198,7 +198,8 @@ typedef struct {
 /* JointsMSELoss pose + KD over all stacks, forward and backward in one pass
  * (lib/core/loss.py:21-39 called 2*S times at lib/core/function.py:128-134):
  *   pose = sum_s 0.5/(B*J*hw) sum w^2 (p_s-g)^2 ; kd likewise against the teacher map t;
- *   dout_s = w^2 [(1-alpha)(p_s-g) + alpha (p_s-t)] / (B*J*hw). */
+ *   dout_s = w^2 [(1-alpha)(p_s-g) + alpha (p_s-t)] / (B*J*hw).
+ * use_target_weight=False (loss.py:30-37) = a weight buffer of ones. */
 #define FPD_MAX_STACKS 8
 typedef struct {
     int32_t B, J, H, W, S, dtype;
@@ -212,6 +213,8 @@ typedef struct {
     double* losses;        /* [2] += {pose, kd}; caller zeroes */
     float grad_scale;      /* extra factor on dout (1/world for DP averaging), normally 1 */
     int32_t _pad;
+    const float* weight_kd; /* optional [B,J]: weights of the distillation term when its criterion's use_target_weight
+                             * differs from the pose criterion's (tools/fpd_train.py:145-147,177-179); NULL = `weight` */
 } fpd_loss_t;
 
 /* torch.optim.Adam(lr) step over one flat fp32 arena (lib/utils/utils.py:69-73), optionally
@@ -281,9 +284,11 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
                      fpd_stream_t stream);
 
 /* Per-step training metric (lib/core/evaluate.py:16-71 accuracy, lib/core/inference.py:18-46 get_max_preds): heat-map
- * arg-max of prediction and target, PCK@thr over the batch.  One call appends {avg_acc, cnt} (what the reference passes to
- * its AverageMeter every iteration, function.py:154-155) to the device log ring at slot *cursor % log_slots and advances
- * the cursor -- no host synchronisation; the host drains the ring when it prints a log line. */
+ * arg-max of prediction and target, PCK@thr over the batch, bit-exact with the reference (first maximum wins; the
+ * normaliser is the reference's [h, w]/10 applied to (x, y), evaluate.py:55; float64 distances and averages).  One call
+ * appends {avg_acc, cnt, pose_loss, kd_loss} (what the reference passes to its AverageMeters every iteration,
+ * function.py:150-155) to the device log ring at slot *cursor % log_slots and advances the cursor -- no host
+ * synchronisation; the host drains the ring when it prints a log line. */
 typedef struct {
     int32_t B, J, H, W, dtype, log_slots;
     float thr;             /* 0.5 in the reference */
@@ -291,8 +296,9 @@ typedef struct {
     const void* out;       /* prediction [B,H,W,J] (NHWC, dtype) */
     const float* target;   /* [B,J,H,W] fp32 (NCHW, as the loader delivers it) */
     float* counts;         /* [J][2] workspace {hits, valid}, zero on entry, zeroed again on exit */
-    float* log;            /* [log_slots][2] */
+    double* log;           /* [log_slots][4] {avg_acc, cnt, pose, kd} */
     long long* cursor;     /* device counter of appended entries */
+    const double* losses;  /* optional [2] {pose, kd} of this iteration (fpd_loss_t.losses), copied into the log entry */
 } fpd_pck_t;
 int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream);
 
@@ -301,7 +307,7 @@ enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
     FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16, FPD_OP_HEAD = 17,
-    FPD_OP_HEAD_FOLD = 18
+    FPD_OP_HEAD_FOLD = 18, FPD_OP_NOP = 19
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;
@@ -319,6 +325,12 @@ int fpd_plan_size(const fpd_plan* p);
  * ignored).  Default for every op: lane 0, no waits = the plain in-order list. */
 #define FPD_MAX_LANES 16
 int fpd_plan_set_schedule(fpd_plan* p, int32_t op, int32_t lane, const int32_t* wait_ops, int32_t n_waits);
+/* Hand-off to streams OUTSIDE the plan (the RCCL gradient all-reduce of one bucket, issued while the rest of the
+ * backward still runs): fpd_plan_mark_event() asks fpd_plan_run() to record an event after op `op` each time it issues
+ * it; fpd_plan_wait_op() makes `stream` wait for the most recent such record (hipStreamWaitEvent; no host sync).
+ * FPD_OP_NOP (args: fpd_memset_t, ignored) launches nothing -- a pure ordering point in a lane. */
+int fpd_plan_mark_event(fpd_plan* p, int32_t op);
+int fpd_plan_wait_op(fpd_plan* p, int32_t op, fpd_stream_t stream);
 /* launch ops [begin,end) on stream (and the plan's side-lane streams, see above) */
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
 /* capture ops [begin,end) into a hipGraph once, then replay it (graph id returned by capture) */

@@ -282,7 +282,10 @@ RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgr
        'conv2': lambda A, op: (run_conv(A, op.a), run_conv(A, op.b)),
        'bneck2': lambda A, op: (run_bneck(A, op.a), run_bneck(A, op.b)),
        'ew2': lambda A, op: (run_ew(A, op.a), run_ew(A, op.b)),
-       'head': run_head, 'head_fold': lambda A, op: None}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
+       'head': run_head, 'head_fold': lambda A, op: None,
+       # the interpreter's wgrad accumulates straight into dw (no slabs): the slab reduction and the bucket marker of
+       # the device plan have no effect on the specification
+       'wreduce': lambda A, op: None, 'grad_ready': lambda A, op: None}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):

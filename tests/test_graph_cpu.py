@@ -12,7 +12,8 @@ from tests import _cases, _interp_util as U
 def build(name, train, which='s', wlp_is_master=True, **kw):
     c = _cases.CONFIGS[name]
     feats, stacks = c[which]
-    table = G.ParamTable(hourglass_ref.hourglass_keys(feats, stacks, c['joints']))
+    # the product's layout: one gradient bucket per stack (lib/models/hourglass.py)
+    table = G.ParamTable(hourglass_ref.hourglass_keys(feats, stacks, c['joints']), bucket_of=G.hourglass_bucket_of(stacks))
     g = G.HourglassGraph(table, feats, stacks, c['joints'], c['batch'], c['image'][1], c['image'][0], train,
                          wlp_is_master=wlp_is_master, **kw)
     return c, table, g
@@ -238,3 +239,43 @@ def test_fused_head_graph_matches_unfused():
         outs.append([A.view(o.buf).clone() for o in g.outputs])
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(a.abs().max()))
+
+
+def test_gradient_buckets_are_contiguous_and_close_in_backward_order():
+    """graph.ParamTable lays the param/grad arena out bucket by bucket (last stack first, stem with stack 0); the backward
+    list closes each bucket with a slab reduction + a 'grad_ready' marker on the weight-gradient lane, and under the
+    multi-lane schedule that marker is ordered after EVERY writer of the bucket's gradient slice (data-parallel
+    all-reduce of the slice starts there, executor.FusedFPDStep.grad_buckets)."""
+    from fpd_amd.schedule import PhaseSchedule
+    c, table, g = build('cfg1', train=True, wlp_is_master=False)
+    S = c['s'][1]
+    assert len(table.buckets) == S
+    assert table.buckets[0][0] == 0 and table.buckets[-1][1] == table.sizes['param']
+    for (a0, a1), (b0, b1) in zip(table.buckets, table.buckets[1:]):
+        assert a1 == b0 and a0 < a1                                        # contiguous, non-empty, no gaps
+    for k in table.trainable_keys():
+        lo, hi = table.buckets[table.bucket[k]]
+        assert lo <= table[k].off and table[k].off + table[k].numel <= hi
+    assert table.bucket['conv1.weight'] == S - 1 and table.bucket['hg.%d.hg.0.0.0.conv1.weight' % (S - 1)] == 0
+    assert table.bucket['fc_.0.weight'] == S - 1 and table.bucket['score.%d.weight' % (S - 1)] == 0
+    # state_dict order is untouched by the placement
+    assert [k for k, _ in table.keys] == [k for k, _ in hourglass_ref.hourglass_keys(c['s'][0], S, c['joints'])]
+    G.plan_memory(g.fwd + g.bwd, reuse_delay=8)
+    phase = [None] + [o for o in g.bwd if o.kind != 'seed']
+    ready = [i for i, o in enumerate(phase) if o is not None and o.kind == 'grad_ready']
+    assert [phase[i].bucket for i in ready] == list(range(S))
+    sch = PhaseSchedule([((o.lane or 0), o.accesses()) if o is not None else (0, None) for o in phase], g.n_lanes)
+    for i in ready:
+        lo, hi = table.buckets[phase[i].bucket]
+        for j, o in enumerate(phase):
+            if o is None or o.kind == 'grad_ready':
+                continue
+            wr = o.accesses()[1]
+            if any(b.arena == 'grad' and b.off < hi and b.off + b.numel > lo for b in wr):
+                assert j < i and sch.happens_before(j, i), (o.kind, j, i)
+    # every weight gradient with a slab is reduced by exactly one bucket reduction, in its own bucket
+    red = [o for o in g.bwd if o.kind == 'wreduce']
+    seen = [id(w) for o in red for w in o.wgrads]
+    assert len(seen) == len(set(seen)) == sum(1 for o in g.bwd if o.kind == 'wgrad')
+    for o in red:
+        assert all(table.bucket[w.dw.name[5:]] == o.bucket for w in o.wgrads)

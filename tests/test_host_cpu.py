@@ -12,6 +12,14 @@ from oracle import fpd_ref, hourglass_ref
 from tests.conftest import ROOT
 
 
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _cfg(feats, stacks, joints, dtype='fp32'):
+    return AD(MODEL=AD(NUM_JOINTS=joints, DTYPE=dtype, EXTRA=AD(NUM_FEATURES=feats, NUM_STACKS=stacks, NUM_BLOCKS=1)))
+
+
 def test_config_merge_like_yacs():
     from fpd_amd.lib.config import cfg
     c = cfg.clone()
@@ -47,39 +55,35 @@ def test_state_dict_interop_and_flat_arena():
     assert abs(w.abs().max().item() - 1 / np.sqrt(8 * 9)) < 0.02 and m.state_dict()['bn1.running_var'].eq(1).all()
 
 
-def _accuracy_numpy(output, target, thr=0.5):
-    """numpy restatement of /root/reference/lib/core/evaluate.py:16-71 + inference.py:18-46 (test oracle)."""
-    def max_preds(hm):
-        b, j, h, w = hm.shape
-        flat = hm.reshape(b, j, -1)
-        idx = flat.argmax(2)
-        mv = flat.max(2)
-        pr = np.stack([idx % w, np.floor(idx / w)], -1).astype(np.float32)
-        pr *= (mv > 0)[..., None]
-        return pr
-    pred, gt = max_preds(output), max_preds(target)
-    h, w = output.shape[2:]
-    norm = np.array([w, h]) / 10.0
-    b, j = pred.shape[:2]
-    accs = []
-    for jj in range(j):
-        d = []
-        for bb in range(b):
-            if gt[bb, jj, 0] > 1 and gt[bb, jj, 1] > 1:
-                d.append(np.linalg.norm(pred[bb, jj] / norm - gt[bb, jj] / norm))
-        if d:
-            accs.append(np.mean(np.array(d) < thr))
-    return float(np.mean(accs)) if accs else 0.0, len(accs)
+def _pck_cases():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pck_ref.npz'))
+    for name in sorted({k.split('/')[0] for k in g.files}):
+        yield name, {k.split('/')[1]: g[k] for k in g.files if k.startswith(name + '/')}
 
 
-def test_accuracy_matches_reference_definition():
+def test_pck_oracle_and_product_match_the_reference_goldens():
+    """tests/golden/pck_ref.npz was produced by the reference's own core.evaluate.accuracy / core.inference.get_max_preds
+    (make_golden_pck.py).  The oracle restatement and the product's torch `accuracy` reproduce (acc, avg_acc, cnt, pred)
+    bit for bit -- square and 64x48 / 96x72 maps (where [h,w]/10 vs [w,h]/10 differ), ties, non-positive maps."""
     from fpd_amd.lib.core.evaluate import accuracy
-    rng = np.random.RandomState(0)
-    _, tg, _ = fpd_ref.synth_batch(3, 4, 16)
-    out = tg.numpy() + 0.3 * rng.standard_normal(tg.shape).astype(np.float32)
-    _, avg, cnt, _ = accuracy(torch.from_numpy(out), tg)
-    ravg, rcnt = _accuracy_numpy(out, tg.numpy())
-    assert cnt == rcnt and abs(avg - ravg) < 1e-6
+    from oracle import pck_ref
+    seen_nonsquare_effect = False
+    for name, c in _pck_cases():
+        out, tg = c['output'].astype(np.float32), c['target'].astype(np.float32)
+        acc, avg, cnt, pred = pck_ref.accuracy(out, tg)
+        np.testing.assert_array_equal(acc, c['acc'], err_msg=name)
+        assert avg == float(c['avg_acc']) and cnt == int(c['cnt']), name
+        np.testing.assert_array_equal(pred, c['pred'], err_msg=name)
+        acc_t, avg_t, cnt_t, pred_t = accuracy(torch.from_numpy(out), torch.from_numpy(tg))
+        np.testing.assert_array_equal(acc_t.numpy(), c['acc'], err_msg=name)
+        assert avg_t == float(c['avg_acc']) and cnt_t == int(c['cnt']), name
+        np.testing.assert_array_equal(pred_t.numpy(), c['pred'], err_msg=name)
+        if out.shape[2] != out.shape[3]:              # the quirk matters: the "corrected" [w,h] order gives another answer
+            h, w = out.shape[2:]
+            d = pck_ref.calc_dists(c['pred'], c['gt'], np.ones((out.shape[0], 2)) * np.array([w, h]) / 10)
+            alt = [pck_ref.dist_acc(d[i]) for i in range(out.shape[1])]
+            seen_nonsquare_effect |= not np.array_equal(np.array(alt), c['acc'][1:])
+    assert seen_nonsquare_effect
 
 
 def test_product_synth_matches_oracle_target_rendering():
@@ -157,3 +161,59 @@ def test_hrnet_factory_fails_loudly():
     from fpd_amd.runtime import FpdError
     with pytest.raises(FpdError, match='HRNet'):
         eval('models.pose_hrnet.get_pose_net')(None, is_train=True)
+
+
+def test_fused_adam_state_dict_interoperates_with_torch_adam_and_resumes():
+    """checkpoint['optimizer'] round trip (tools/fpd_train.py:224-234 AUTO_RESUME): FusedAdam's state dict has
+    torch.optim.Adam's layout (so the reference's Adam can load it and vice versa), keeps 'initial_lr', and the
+    closed-form MultiStepLR reproduces the reference's schedule (scheduler stepped at the START of each epoch) on a
+    fresh run and on a resumed one alike."""
+    from fpd_amd.lib.models import hourglass
+    from fpd_amd.lib.utils.utils import FusedAdam, multistep_lr
+    m = hourglass.get_pose_net(_cfg(32, 1, 4), is_train=True)
+    opt = FusedAdam(m, lr=1e-3)
+    params = list(m.parameters())
+    ref = torch.optim.Adam(params, lr=1e-3)
+    gen = torch.Generator().manual_seed(0)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=gen)
+    ref.step(); ref.step()
+    sd_ref = ref.state_dict()
+    sd_ref['param_groups'][0]['initial_lr'] = 1e-3
+    sd_ref['param_groups'][0]['lr'] = 1e-4                       # a decayed lr, as a checkpoint written after a milestone has
+    opt.load_state_dict(sd_ref)                                  # reference (torch Adam) checkpoint -> FusedAdam
+    assert int(opt.step_dev) == 2 and opt.param_groups[0]['lr'] == 1e-4 and opt.param_groups[0]['initial_lr'] == 1e-3
+    for (mv, vv), p in zip(zip(opt._views(opt.m), opt._views(opt.v)), params):
+        torch.testing.assert_close(mv, ref.state[p]['exp_avg'], rtol=0, atol=0)
+        torch.testing.assert_close(vv, ref.state[p]['exp_avg_sq'], rtol=0, atol=0)
+    sd = opt.state_dict()                                        # FusedAdam checkpoint -> torch Adam
+    ref2 = torch.optim.Adam(params, lr=5.0)
+    ref2.load_state_dict(sd)
+    assert ref2.param_groups[0]['lr'] == 1e-4 and ref2.param_groups[0]['initial_lr'] == 1e-3
+    for p in params:
+        torch.testing.assert_close(ref2.state[p]['exp_avg'], ref.state[p]['exp_avg'], rtol=0, atol=0)
+        assert float(ref2.state[p]['step']) == 2
+    opt2 = FusedAdam(m, lr=7.0)                                  # and back into a fresh FusedAdam (AUTO_RESUME)
+    opt2.load_state_dict(torch.load(_roundtrip(sd), weights_only=False))
+    assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v) and int(opt2.step_dev) == 2
+    assert opt2.param_groups[0]['initial_lr'] == 1e-3
+    # a fresh optimizer's state dict has no per-parameter state, like torch's
+    assert FusedAdam(m, lr=1e-3).state_dict()['state'] == {}
+    # schedule: reference = MultiStepLR(milestones, gamma, last_epoch=-1) stepped at the start of every epoch
+    import warnings
+    o = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2.5e-4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sch = torch.optim.lr_scheduler.MultiStepLR(o, [3, 5], 0.1, last_epoch=-1)
+        for epoch in range(8):
+            sch.step()                                           # tools/fpd_train.py:253
+            assert abs(o.param_groups[0]['lr'] - multistep_lr(2.5e-4, [3, 5], 0.1, epoch)) < 1e-12, epoch
+    assert multistep_lr(1.0, [3, 5], 0.1, 1) == 1.0 and abs(multistep_lr(1.0, [3, 5], 0.1, 2) - 0.1) < 1e-15
+
+
+def _roundtrip(obj):
+    import io
+    buf = io.BytesIO()
+    torch.save(obj, buf)
+    buf.seek(0)
+    return buf

@@ -4,11 +4,14 @@
 Tolerances (stated per test): fp32 build -- abs 2e-4 on O(1..10) values (accumulation-order noise only; the
 fp32 MFMA is an exact fp32 fma chain); bf16 build -- compared with the interpreter run with bf16 storage
 (same rounding points), abs/rel 2e-2."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import plan_interp as PI
+from tests.conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -567,38 +570,34 @@ def test_bottleneck_pair():
 
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_pck_metric(dtype):
-    """fpd_pck (arg-max + PCK@0.5 on the device) vs lib.core.evaluate.accuracy (torch restatement of the reference's
-    numpy metric, itself pinned against a numpy port in tests/test_host_cpu.py): identical (avg_acc, cnt), incl. ties,
-    all-non-positive maps (coordinates zeroed) and targets near the corner (excluded)."""
-    from fpd_amd.lib.core.evaluate import DeviceAccuracy, accuracy
-    B, J, H, W = 6, 16, 64, 64
-    gen = torch.Generator().manual_seed(3)
+    """fpd_pck (arg-max + PCK@0.5 on the device) against the goldens written by the REFERENCE's own evaluate.accuracy
+    (tests/golden/pck_ref.npz; square, 64x48 and 96x72 maps, ties, non-positive maps, corner targets, joints without a
+    valid sample): (avg_acc, cnt) bit-exact in fp32.  bf16 storage rounds the prediction, so there the checker is the
+    oracle restatement (itself pinned to the same goldens) on the rounded maps.  The loss accumulators handed to the
+    kernel come back in the same log entry."""
+    import numpy as np
+    from fpd_amd.lib.core.evaluate import DeviceAccuracy
+    from oracle import pck_ref
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pck_ref.npz'))
     tdt = torch.bfloat16 if dtype == 1 else torch.float32
-    for trial in range(3):
-        tgt = torch.zeros(B, J, H, W)
-        out = (0.05 * torch.randn(B, J, H, W, generator=gen))
-        for b in range(B):
-            for j in range(J):
-                gx, gy = int(torch.randint(0, W, (1,), generator=gen)), int(torch.randint(0, H, (1,), generator=gen))
-                if (b + j) % 7 != 0:
-                    tgt[b, j, gy, gx] = 1.0                       # else: empty target (max 0 -> coordinates (0,0) -> not counted)
-                dx, dy = (int(torch.randint(-4, 5, (1,), generator=gen)) for _ in range(2))
-                px, py = min(max(gx + dx, 0), W - 1), min(max(gy + dy, 0), H - 1)
-                out[b, j, py, px] = 1.0
-                if (b * J + j) % 5 == 0:
-                    out[b, j, min(py + 1, H - 1), px] = 1.0       # tie: the first maximum must win
-                if (b * J + j) % 11 == 0:
-                    out[b, j] = -out[b, j].abs()                  # nothing positive: prediction collapses to (0, 0)
-        out_r = out.to(tdt).float()
-        _, avg, cnt, _ = accuracy(out_r, tgt)
-        dev = torch.device('cuda:0')
+    dev = torch.device('cuda:0')
+    for name in sorted({k.split('/')[0] for k in g.files}):
+        out, tg = torch.from_numpy(g[name + '/output'].astype(np.float32)), torch.from_numpy(g[name + '/target'].astype(np.float32))
+        B, J, H, W = out.shape
+        if dtype == 1:
+            _, avg, cnt, _ = pck_ref.accuracy(out.to(tdt).float().numpy(), tg.numpy())
+        else:
+            avg, cnt = float(g[name + '/avg_acc']), int(g[name + '/cnt'])
         out_nhwc = out.permute(0, 2, 3, 1).contiguous().to(tdt).to(dev)
-        tgt_d = tgt.to(dev)
-        m = DeviceAccuracy(B, J, H, W, dtype, dev, slots=8).bind(out_nhwc.data_ptr(), tgt_d.data_ptr())
+        tgt_d = tg.to(dev)
+        losses = torch.tensor([0.125, 0.75], dtype=torch.float64, device=dev)
+        m = DeviceAccuracy(B, J, H, W, dtype, dev, slots=8).bind(out_nhwc.data_ptr(), tgt_d.data_ptr(), losses.data_ptr())
         m.enqueue(); m.enqueue()
-        got = m.drain()
+        assert m.pending() == 2
+        got = m.drain(full=True)
         assert len(got) == 2 and got[0] == got[1], got            # counters are re-zeroed between calls
-        assert got[0][1] == cnt and abs(got[0][0] - avg) < 1e-6, (got[0], avg, cnt)
+        assert got[0][1] == cnt and got[0][0] == avg, (name, got[0], avg, cnt)
+        assert got[0][2:] == (0.125, 0.75)
         assert m.drain() == []
 
 

@@ -27,9 +27,9 @@ import torch.utils.data  # noqa: E402
 from fpd_amd import dist as fdist, executor as E, synth  # noqa: E402
 from fpd_amd.lib import models  # noqa: E402,F401
 from fpd_amd.lib.config import cfg, update_config  # noqa: E402
-from fpd_amd.lib.core.function import fpd_train  # noqa: E402
+from fpd_amd.lib.core.function import fpd_train, train  # noqa: E402
 from fpd_amd.lib.core.loss import JointsMSELoss  # noqa: E402
-from fpd_amd.lib.utils.utils import get_optimizer, load_checkpoint, save_checkpoint  # noqa: E402
+from fpd_amd.lib.utils.utils import get_optimizer, load_checkpoint, multistep_lr, save_checkpoint  # noqa: E402
 
 
 def parse_args():
@@ -95,8 +95,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     train_type = get_train_type(cfg.KD.TRAIN_TYPE, cfg.KD.TEACHER)
-    if train_type != 'FPD':
-        sys.exit('this entry point implements the FPD path; set KD.TRAIN_TYPE FPD (plain training is out of scope)')
     out_dir = os.path.join(cfg.OUTPUT_DIR, cfg.DATASET.DATASET, cfg.MODEL.NAME,
                            os.path.basename(args.cfg).split('.')[0])
     os.makedirs(out_dir, exist_ok=True)
@@ -106,16 +104,20 @@ def main():
     tcfg = cfg.clone()                                                                        # :128-131
     if args.tcfg:
         tcfg.merge_from_file(args.tcfg)
-    torch.manual_seed(2)
-    tmodel = eval('models.' + tcfg.MODEL.NAME + '.get_pose_net')(tcfg, is_train=False)       # :135-137
-    if cfg.KD.TEACHER != 'synthetic':
-        load_checkpoint(cfg.KD.TEACHER, tmodel, strict=True, model_info='teacher_' + tcfg.MODEL.NAME)   # :139-141
+    tmodel = None
+    if train_type == 'FPD':
+        torch.manual_seed(2)
+        tmodel = eval('models.' + tcfg.MODEL.NAME + '.get_pose_net')(tcfg, is_train=False)   # :135-137
+        if cfg.KD.TEACHER != 'synthetic':
+            load_checkpoint(cfg.KD.TEACHER, tmodel, strict=True, model_info='teacher_' + tcfg.MODEL.NAME)   # :139-141
+        tmodel = fdist.DataParallelReplica(tmodel.to(dev))
     if cfg.TRAIN.CHECKPOINT:
         load_checkpoint(cfg.TRAIN.CHECKPOINT, model, strict=True, model_info='student_' + cfg.MODEL.NAME)
-    model, tmodel = fdist.DataParallelReplica(model.to(dev)), fdist.DataParallelReplica(tmodel.to(dev))
+    model = fdist.DataParallelReplica(model.to(dev))
     if world > 1:
         fdist.broadcast_state(dist, model.module)
-        fdist.broadcast_state(dist, tmodel.module)
+        if tmodel is not None:
+            fdist.broadcast_state(dist, tmodel.module)
 
     pose_criterion = JointsMSELoss(use_target_weight=cfg.LOSS.USE_TARGET_WEIGHT).to(dev)     # :145-147,177-179
     kd_pose_criterion = JointsMSELoss(use_target_weight=tcfg.LOSS.USE_TARGET_WEIGHT).to(dev)
@@ -138,7 +140,7 @@ def main():
             def __len__(self):
                 return min(len(full), args.max_iters)
         loader = _Limited()
-    if cfg.KD.TEACHER == 'synthetic':          # give the random teacher sane eval-mode BN statistics once
+    if tmodel is not None and cfg.KD.TEACHER == 'synthetic':          # give the random teacher sane eval-mode BN statistics once
         x0 = next(iter(loader))[0]
         t = tmodel.module
         cal = E.GraphInstance(t.device_state(), t.cfg_hg, x0.shape[0], x0.shape[2], x0.shape[3], train=True).finalize()
@@ -156,15 +158,19 @@ def main():
         model.load_state_dict(state['state_dict'])
         optimizer.load_state_dict(state['optimizer'])
         logger.info("=> loaded checkpoint '%s' (epoch %d)", ckpt, state['epoch'])
-    sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR,
-                                                 last_epoch=begin_epoch - 1)                  # :236-239
+    base_lr = float(optimizer.param_groups[0].get('initial_lr', cfg.TRAIN.LR))               # :236-239 MultiStepLR
+    optimizer.param_groups[0]['initial_lr'] = base_lr
     allreduce = fdist.make_allreduce(dist) if world > 1 else None
     writer_dict = {'writer': None, 'train_global_steps': 0, 'valid_global_steps': 0}
     for epoch in range(begin_epoch, cfg.TRAIN.END_EPOCH):                                     # :252-286
         t0 = time.time()
-        loss = fpd_train(cfg, loader, model, tmodel, pose_criterion, kd_pose_criterion, optimizer, epoch, out_dir,
-                         cfg.LOG_DIR, writer_dict, allreduce=allreduce, world_size=world)
-        sched.step()
+        optimizer.param_groups[0]['lr'] = multistep_lr(base_lr, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR, epoch)   # :253
+        if train_type == 'FPD':                                                               # :255-264
+            loss = fpd_train(cfg, loader, model, tmodel, pose_criterion, kd_pose_criterion, optimizer, epoch, out_dir,
+                             cfg.LOG_DIR, writer_dict, allreduce=allreduce, world_size=world)
+        else:
+            loss = train(cfg, loader, model, pose_criterion, optimizer, epoch, out_dir, cfg.LOG_DIR, writer_dict,
+                         allreduce=allreduce, world_size=world)
         torch.cuda.synchronize()
         logger.info('=> epoch %d done in %.1fs, %.1f samples/s, last logged loss %.5f', epoch, time.time() - t0,
                     len(loader) * bs * world / max(time.time() - t0, 1e-9), loss)
