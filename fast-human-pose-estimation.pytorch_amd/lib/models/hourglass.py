@@ -6,10 +6,16 @@ API mirrored from /root/reference/lib/models/hourglass.py:
   * state_dict keys / shapes identical (conv OIHW, BN weight/bias/running_*/num_batches_tracked), so
     reference checkpoints load with strict=True (tools/fpd_train.py:139-141, lib/utils/utils.py:250-255)
   * .train()/.eval() switch BatchNorm between batch and running statistics (lib/core/function.py:110-111)
-What differs by design: parameters are views into one flat HBM arena (conv weights channels-last), the
-forward/backward run as a recorded plan of hand-written gfx950 kernels, and a CPU input is an error --
-there is no eager/CPU fallback (the reference's CPU dry-runs for add_graph/get_model_summary at
-tools/fpd_train.py:162-167 must be given a CUDA tensor).
+  * the module tree has the reference's classes, names and registration order (HourglassNet / Hourglass /
+    Bottleneck containers; Conv2d, BatchNorm2d, ReLU, MaxPool2d, Upsample leaves), so named_modules(),
+    isinstance(m, nn.Conv2d) loops and per-layer forward hooks see what they see on the reference
+What differs by design: parameters are views into one flat HBM arena (conv weights channels-last) and the
+forward/backward run as ONE recorded plan of hand-written gfx950 kernels -- the leaf modules carry parameters
+and metadata but are never called, and calling one (or giving the model a CPU tensor) is an error: there is no
+eager/CPU fallback.  What the reference does through CPU dry-runs (tools/fpd_train.py:162-167) is served by
+`HourglassNet.shape_forward()`: it walks the modules in the reference's execution order and fires their forward
+hooks with shape-only (meta-device) tensors, which is all `utils.get_model_summary` needs; tensorboard's
+`add_graph` (a JIT trace of torch ops) has no counterpart.
 """
 import math
 
@@ -67,8 +73,69 @@ def hourglass_keys(num_feats, num_stacks, num_joints, num_blocks=1, depth=4):
     return keys
 
 
-class _Node(nn.Module):
-    """Container reproducing one level of the reference's module tree (names only; no compute)."""
+def _no_eager(self, *a, **kw):
+    raise R.FpdError('%s is executed inside the fused HIP plan of its HourglassNet (model(x) on a CUDA tensor); the '
+                     'leaf modules hold parameters/metadata only -- there is no eager torch path' % type(self).__name__)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d metadata + parameters (views of the model's flat arena); storage-less construction."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=True, device='meta')
+    forward = _no_eager
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def __init__(self, c):
+        super().__init__(c, momentum=BN_MOMENTUM, device='meta')
+    forward = _no_eager
+
+
+class ReLU(nn.ReLU):
+    forward = _no_eager
+
+
+class MaxPool2d(nn.MaxPool2d):
+    forward = _no_eager
+
+
+class Upsample(nn.Upsample):
+    forward = _no_eager
+
+
+class Bottleneck(nn.Module):
+    """hourglass.py:11-52 (pre-activation, expansion 2): container of bn1, conv1, bn2, conv2, bn3, conv3, relu, downsample."""
+    expansion = 2
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.bn1 = BatchNorm2d(inplanes)
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, padding=1)
+        self.bn3 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, 2 * planes, 1)
+        self.relu = ReLU(inplace=True)
+        self.downsample = nn.Sequential(Conv2d(inplanes, 2 * planes, 1)) if inplanes != 2 * planes else None
+        self.stride = 1
+    forward = _no_eager
+
+
+def _residual(inplanes, planes, num_blocks):
+    return nn.Sequential(*[Bottleneck(inplanes if b == 0 else 2 * planes, planes) for b in range(num_blocks)])
+
+
+class Hourglass(nn.Module):
+    """hourglass.py:55-95: hg[d][j] residual sequences (4 at the innermost level, 3 elsewhere) + the nearest x2 upsample."""
+
+    def __init__(self, num_blocks, planes, depth):
+        super().__init__()
+        self.depth = depth
+        self.upsample = Upsample(scale_factor=2)
+        self.hg = nn.ModuleList([nn.ModuleList([_residual(2 * planes, planes, num_blocks) for _ in range(4 if d == 0 else 3)])
+                                 for d in range(depth)])
+    forward = _no_eager
 
 
 class _HourglassFn(torch.autograd.Function):
@@ -138,29 +205,48 @@ class HourglassNet(nn.Module):
         return v
 
     def _build_tree(self):
+        """The reference's module tree (hourglass.py:100-168) in its registration order, then every parameter / buffer
+        re-pointed at its view of the flat arenas."""
+        F_, S, J, nb = self.cfg_hg['F'], self.cfg_hg['S'], self.cfg_hg['J'], self.cfg_hg['num_blocks']
+        inpl, nf = F_ // 4, F_ // 2
+        self.inplanes, self.num_feats = 2 * nf, nf
+        self.conv1 = Conv2d(3, inpl, 7, stride=2, padding=3)
+        self.bn1 = BatchNorm2d(inpl)
+        self.relu = ReLU(inplace=True)
+        self.layer1 = _residual(inpl, inpl, 1)
+        self.layer2 = _residual(2 * inpl, 2 * inpl, 1)     # hourglass.py:121: planes = the running self.inplanes
+        self.layer3 = _residual(4 * inpl, nf, 1)
+        self.maxpool = MaxPool2d(2, stride=2)
+        ch = 2 * nf
+        self.hg = nn.ModuleList([Hourglass(nb, nf, 4) for _ in range(S)])
+        self.res = nn.ModuleList([_residual(ch, nf, nb) for _ in range(S)])
+        self.fc = nn.ModuleList([nn.Sequential(Conv2d(ch, ch, 1), BatchNorm2d(ch), self.relu) for _ in range(S)])
+        self.score = nn.ModuleList([Conv2d(ch, J, 1) for _ in range(S)])
+        self.fc_ = nn.ModuleList([Conv2d(ch, ch, 1) for _ in range(S - 1)])
+        self.score_ = nn.ModuleList([Conv2d(J, ch, 1) for _ in range(S - 1)])
         for key, _ in self.table.keys:
-            parts = key.split('.')
-            node = self
-            for p in parts[:-1]:
-                if p not in node._modules:
-                    node.add_module(p, _Node())
-                node = node._modules[p]
-            leaf = parts[-1]
+            node, leaf = self._owner(key)
             if self.table[key].arena == 'param':
-                node.register_parameter(leaf, nn.Parameter(self._view(key)))
+                node._parameters[leaf] = nn.Parameter(self._view(key))
             else:
-                node.register_buffer(leaf, self._view(key))
+                node._buffers[leaf] = self._view(key)
+        meta = [k for k, v in list(self.named_parameters()) + list(self.named_buffers()) if v.is_meta]
+        assert not meta, 'module tree and key table disagree: %r' % meta[:4]
+
+    def _owner(self, key):
+        parts = key.split('.')
+        node = self
+        for p in parts[:-1]:
+            node = node._modules[p]
+        return node, parts[-1]
 
     def _relink(self):
         for key, _ in self.table.keys:
-            parts = key.split('.')
-            node = self
-            for p in parts[:-1]:
-                node = node._modules[p]
+            node, leaf = self._owner(key)
             if self.table[key].arena == 'param':
-                node._parameters[parts[-1]].data = self._view(key)
+                node._parameters[leaf].data = self._view(key)
             else:
-                node._buffers[parts[-1]] = self._view(key)
+                node._buffers[leaf] = self._view(key)
 
     def _apply(self, fn, recurse=True):
         # move / cast the flat arenas as a whole, then re-point every parameter and buffer at them
@@ -216,11 +302,72 @@ class HourglassNet(nn.Module):
 
     def _attach_grads(self):
         for key in self.table.trainable_keys():
-            parts = key.split('.')
-            node = self
-            for p in parts[:-1]:
-                node = node._modules[p]
-            node._parameters[parts[-1]].grad = self._view(key, grad=True)
+            node, leaf = self._owner(key)
+            node._parameters[leaf].grad = self._view(key, grad=True)
+
+    # ---- shape-only walk in the reference's execution order (hourglass.py:32-52,80-92,170-192) ----
+    def shape_forward(self, input_shape):
+        """Fire every module's forward hooks, in the order the reference's forward would, with shape-only (meta-device)
+        tensors; returns the list of output shapes.  This is what `utils.get_model_summary` and other hook-based
+        inspection tools get instead of the reference's CPU dry-run (the compute itself is one fused plan)."""
+        def fire(m, ishape, oshape):
+            if m._forward_hooks:
+                ti = torch.empty(tuple(ishape), device='meta')
+                to = [torch.empty(tuple(o), device='meta') for o in oshape] if isinstance(oshape, list) else \
+                    torch.empty(tuple(oshape), device='meta')
+                for h in list(m._forward_hooks.values()):
+                    h(m, (ti,), to)
+            return oshape
+
+        def conv(m, s):
+            n, c, h, w = s
+            assert c == m.in_channels, (c, m.in_channels)
+            k, st, p = m.kernel_size[0], m.stride[0], m.padding[0]
+            return fire(m, s, (n, m.out_channels, (h + 2 * p - k) // st + 1, (w + 2 * p - k) // st + 1))
+
+        def same(m, s):
+            return fire(m, s, s)
+
+        def block(b, s):
+            o = same(b.relu, same(b.bn1, s))
+            o = conv(b.conv1, o)
+            o = conv(b.conv2, same(b.relu, same(b.bn2, o)))
+            o = conv(b.conv3, same(b.relu, same(b.bn3, o)))
+            if b.downsample is not None:
+                fire(b.downsample, s, conv(b.downsample[0], s))
+            return fire(b, s, o)
+
+        def seq(q, s):
+            o = s
+            for b in q:
+                o = block(b, o)
+            return fire(q, s, o)
+
+        def hour(hgm, n, s):
+            up1 = seq(hgm.hg[n - 1][0], s)
+            low = (s[0], s[1], s[2] // 2, s[3] // 2)                 # F.max_pool2d: functional, no module, no hook
+            low = seq(hgm.hg[n - 1][1], low)
+            low = hour(hgm, n - 1, low) if n > 1 else seq(hgm.hg[n - 1][3], low)
+            low = seq(hgm.hg[n - 1][2], low)
+            fire(hgm.upsample, low, up1)
+            return up1
+
+        x = same(self.relu, same(self.bn1, conv(self.conv1, tuple(input_shape))))
+        x = seq(self.layer1, x)
+        x = fire(self.maxpool, x, (x[0], x[1], x[2] // 2, x[3] // 2))
+        x = seq(self.layer3, seq(self.layer2, x))
+        outs = []
+        for i in range(self.num_stacks):
+            y = fire(self.hg[i], x, hour(self.hg[i], self.hg[i].depth, x))
+            y = seq(self.res[i], y)
+            f = self.fc[i]
+            y = fire(f, y, same(f[2], same(f[1], conv(f[0], y))))
+            sc = conv(self.score[i], y)
+            outs.append(sc)
+            if i < self.num_stacks - 1:
+                conv(self.fc_[i], y)
+                conv(self.score_[i], sc)
+        return outs
 
     def instance(self, shape, train):
         key = (tuple(shape), bool(train))

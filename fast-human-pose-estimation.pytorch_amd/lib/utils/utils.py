@@ -120,6 +120,63 @@ def get_optimizer(cfg, model):
     raise ValueError('unknown optimizer %r' % cfg.TRAIN.OPTIMIZER)
 
 
+def get_model_summary(model, *input_tensors, item_length=26, verbose=False):
+    """utils.py:86-202: per-layer table (name, input size, output size, parameters, multiply-adds) collected by forward
+    hooks on every non-container module.  The reference obtains it from a CPU dry-run; the HIP-backed models execute as
+    one fused plan, so the hooks are fired by `model.shape_forward(input_shape)` instead -- the same modules in the same
+    order with shape-only (meta) tensors, which is everything the hooks read.  Same text as the reference's."""
+    import os as _os
+    import torch.nn as nn
+    summary, hooks, instances = [], [], {}
+
+    def hook(module, inp, output):
+        cls = type(module).__name__
+        instances[cls] = instances.get(cls, 0) + 1
+        params = 0
+        if 'Conv' in cls or 'BatchNorm' in cls or 'Linear' in cls:
+            params = sum(p.numel() for p in module.parameters())
+        flops = 'Not Available'
+        if 'Conv' in cls and hasattr(module, 'weight'):
+            flops = int(module.weight.numel())
+            for d in list(output.size())[2:]:
+                flops *= int(d)
+        elif isinstance(module, nn.Linear):
+            flops = int(output.numel()) * int(inp[0].size(1))
+        out0 = output[0] if isinstance(output, list) else output
+        summary.append(('%s_%d' % (cls, instances[cls]), list(inp[0].size()), list(out0.size()), params, flops))
+
+    target = model.module if hasattr(model, 'module') and hasattr(model.module, 'shape_forward') else model
+    def add_hooks(m):                       # utils.py:147-152 via nn.Module.apply: a module shared by several parents
+        if not isinstance(m, (nn.ModuleList, nn.Sequential)) and m is not target:      # (the model's ReLU) is visited, and
+            hooks.append(m.register_forward_hook(hook))                                # hooked, once per parent
+    target.apply(add_hooks)
+    target.eval()
+    try:
+        target.shape_forward(tuple(input_tensors[0].shape))
+    finally:
+        for h in hooks:
+            h.remove()
+    sp, nl = item_length, _os.linesep
+    rule = '-' * sp * 5 + nl
+    details = ''
+    if verbose:
+        heads = ('Name', 'Input Size', 'Output Size', 'Parameters', 'Multiply Adds (Flops)')
+        details = 'Model Summary' + nl + ''.join(h + ' ' * (sp - len(h)) for h in heads) + nl + rule
+    params_sum = flops_sum = 0
+    for row in summary:
+        params_sum += row[3]
+        if row[4] != 'Not Available':
+            flops_sum += row[4]
+        if verbose:
+            details += ''.join(str(c) + ' ' * (sp - len(str(c))) for c in row) + nl + rule
+    details += nl + 'Total Parameters: {:,}'.format(params_sum) + nl + rule
+    details += 'Total Multiply Adds (For Convolution and Linear Layers only): {:,} GFLOPs'.format(flops_sum / (1024 ** 3)) + nl + rule
+    details += 'Number of Layers' + nl
+    for cls in instances:
+        details += '{} : {} layers   '.format(cls, instances[cls])
+    return details
+
+
 def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth'):
     """utils.py:78-83."""
     torch.save(states, os.path.join(output_dir, filename))

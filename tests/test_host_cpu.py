@@ -217,3 +217,52 @@ def _roundtrip(obj):
     torch.save(obj, buf)
     buf.seek(0)
     return buf
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no torch.distributed environment re-executes itself under torch.distributed.run
+    (one rank per GPU, 127.0.0.1 rendezvous) and rank 0 prints ONE JSON line with n_gpus = 2.  Here: gloo + a stub step
+    (FPD_BENCH_STUB) -- the launch path, the bucketed all-reduce hook and the timing contract, no GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['FPD_BENCH_STUB'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['data'] == 'stub'
+    assert out['config']['ranks'] == 2 and out['config']['allreduce_ok'] is True
+    # a launcher/flag mismatch is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and 'started 1 ranks' in (r2.stderr + r2.stdout)
+
+
+def test_module_tree_hooks_and_model_summary_match_the_reference():
+    """SURVEY section 8(b) module-tree conventions: real leaf modules with the reference's classes/names, forward hooks
+    on every non-container module fire in the reference's execution order (HourglassNet.shape_forward), and
+    utils.get_model_summary reproduces the reference's text (tests/golden/summary_hg2x64.txt, written by the reference's
+    own get_model_summary over its own hourglass.py)."""
+    import torch.nn as nn
+    from fpd_amd import runtime as R
+    from fpd_amd.lib.models import hourglass
+    from fpd_amd.lib.utils.utils import get_model_summary
+    m = hourglass.get_pose_net(_cfg(64, 2, 16), is_train=True)
+    names = dict(m.named_modules())
+    assert isinstance(names['conv1'], nn.Conv2d) and names['conv1'].kernel_size == (7, 7) and names['conv1'].stride == (2, 2)
+    assert isinstance(names['hg.1.hg.0.3.0.bn2'], nn.BatchNorm2d) and names['hg.1.hg.0.3.0.bn2'].momentum == 0.1
+    assert isinstance(names['hg.0.upsample'], nn.Upsample) and isinstance(names['maxpool'], nn.MaxPool2d)
+    assert m.fc[0][2] is m.relu                                     # _make_fc shares the model's ReLU
+    w = names['layer1.0.conv2'].weight
+    assert tuple(w.shape) == (16, 16, 3, 3) and not w.is_meta and w.data_ptr() >= m._flat['param'].data_ptr()
+    with pytest.raises(R.FpdError):
+        names['conv1'](torch.zeros(1, 3, 8, 8))                                 # no eager path hides behind the tree
+    gold = open(os.path.join(ROOT, 'tests', 'golden', 'summary_hg2x64.txt')).read()
+    terse, verbose = gold.split('\n=====VERBOSE=====\n')
+    x = torch.rand(1, 3, 256, 256)
+    assert get_model_summary(m, x) == terse
+    assert get_model_summary(m, x, verbose=True) == verbose
+    assert not any(mod._forward_hooks for mod in m.modules())                   # hooks removed again
