@@ -1,0 +1,254 @@
+"""Accuracy statement for the BENCHMARKED build (bf16 storage + bf16 MFMA, fp32 accumulate; BASELINE.json configs[1]).
+
+The fp32 parity build is pinned to the reference within the 1e-4 criterion (test_model_gpu.py, test_fullsize_gpu.py).
+bf16 cannot meet 1e-4: bf16 WEIGHTS alone move this synthetic random-init network's heat-maps by ~30 % (relative L2) and
+a briefly trained one by ~3-6 % (tools/probes/bf16_study.py, CPU) -- the network amplifies 0.4 % perturbations by the
+same factor that turns fp32's 1e-7 into 4e-4.  The criterion here is therefore the one the fp32 build is held to, at this
+precision: with the fp64 oracle as referee, the bf16 product must never be less accurate than 1.5x THE REFERENCE ITSELF
+RUN AT bf16 (the oracle restatement of lib/core/function.py:119-147 under torch.autocast(bfloat16): bf16 convolutions with
+fp32 accumulation, bf16 activations -- what a user of the reference gets when asking PyTorch for this dtype), for
+  * the teacher heat-map and every student heat-map (relative L2),
+  * pose / KD / total loss (relative), the whole student gradient vector (relative L2),
+  * a 20-step Adam loss trajectory,
+at the golden cfg-1 size and at the full benchmark size (B=32, 256x256, hg4x128 <- hg8x256), plus absolute ceilings so
+that a broken kernel cannot hide behind a noisy checker.  Measured values are printed (pytest -s) and quoted in DESIGN.md."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fpd_ref, hourglass_ref
+from tests import _cases
+
+pytestmark = pytest.mark.gpu
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _cfg(feats, stacks, joints, dtype):
+    return AD(MODEL=AD(NUM_JOINTS=joints, DTYPE=dtype, EXTRA=AD(NUM_FEATURES=feats, NUM_STACKS=stacks, NUM_BLOCKS=1)))
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def grads_rel(g, t):
+    num = sum(float(((g[k].double().cpu() - t[k].double().cpu()) ** 2).sum()) for k in t)
+    den = sum(float((t[k].double() ** 2).sum()) for k in t)
+    return (num / den) ** 0.5
+
+
+def student_step(sd, xin, tgt, wgt, tmap, stacks, autocast=None):
+    """function.py:119-147 with a given teacher map; autocast = device type -> the reference at bf16."""
+    names = fpd_ref.param_names(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+        sd[k].grad = None
+    if autocast:
+        with torch.autocast(autocast, dtype=torch.bfloat16):
+            outs = hourglass_ref.hourglass_forward(sd, xin, stacks, train=True)
+        outs = [o.float() for o in outs]
+    else:
+        outs = hourglass_ref.hourglass_forward(sd, xin, stacks, train=True)
+    pose, kd, loss = fpd_ref.fpd_losses(outs, tmap, tgt, wgt, 0.5)
+    loss.backward()
+    g = {k: sd[k].grad.detach().clone() for k in names}
+    for k in names:
+        sd[k].requires_grad_(False)
+    return [o.detach() for o in outs], (float(pose), float(kd), float(loss)), g
+
+
+def product_step(student, teacher, x, tg, tw, tmap_fixed, B, H, W):
+    """bf16 product: teacher forward, then the student phases by hand against the GIVEN teacher map."""
+    from fpd_amd import executor as E
+    step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5)
+    step.set_batch(x, tg, tw)
+    step.teacher_async(x)
+    s = step.student
+    torch.cuda.current_stream().wait_event(step.ev_t[0])
+    torch.cuda.synchronize()
+    J = tg.shape[1]
+    ours_tmap = step.tmap[0].view(B, H // 4, W // 4, J).permute(0, 3, 1, 2).float().cpu()
+    step.tmap[0].copy_(tmap_fixed.permute(0, 2, 3, 1).reshape(-1).to(step.tmap[0].dtype))     # same KD target for everyone
+    s.run('prep'); s.run('fwd'); s.run('mid'); s.run('bwd')
+    torch.cuda.synchronize()
+    maps = [s.output_view(i).permute(0, 3, 1, 2).float().cpu() for i in range(len(s.g.outputs))]
+    student._attach_grads()
+    grads = {k: p.grad.detach().float().cpu().clone() for k, p in student.named_parameters()}
+    return ours_tmap, maps, step.losses(), grads
+
+
+def check(label, ours, ref_bf16, floor, ceiling, slack=1.5):
+    print('%-34s ours %.3e   reference@bf16 %.3e   (floor %.1e, ceiling %.1e)' % (label, ours, ref_bf16, floor, ceiling))
+    assert ours <= max(floor, slack * ref_bf16), (label, 'less accurate than %.1fx the reference at bf16' % slack, ours, ref_bf16)
+    assert ours <= ceiling, (label, 'above the absolute ceiling', ours, ceiling)
+
+
+def test_cfg1_bf16_step_vs_reference_at_bf16():
+    """Golden cfg-1 (hg2x64 <- hg2x64, B=2, 256x256; weights / calibrated BN from tests/golden): referee fp64 on the CPU,
+    reference-at-bf16 = the oracle under CPU autocast."""
+    from tests.test_model_gpu import build_models
+    name = 'cfg1'
+    c, gold, student, teacher = build_models(name, 'bf16')
+    s_sd, t_sd = _cases.state_dicts(name, gold)
+    x, tg, tw = _cases.batch(name, 0)
+    B, (W, H) = c['batch'], c['image']
+    tr = _cases.truth64(name)
+    with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        a_tmap = hourglass_ref.hourglass_forward(t_sd, x, c['t'][1], train=False)[-1].float()
+    tmap_fixed = torch.from_numpy(gold['toutput']).to(torch.bfloat16).float()           # bf16-representable KD target
+    ours_tmap, maps, losses, grads = product_step(student, teacher, x, tg, tw, tmap_fixed, B, H, W)
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
+    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), c['s'][1])
+    a_maps, a_loss, a_grads = student_step({k: v.clone() for k, v in s_sd.items()}, x, tg, tw, tmap_fixed, c['s'][1], autocast='cpu')
+    check('cfg1 teacher map rel-L2', rel(ours_tmap, tr['toutput']), rel(a_tmap, tr['toutput']), 2e-2, 0.6)
+    for i in range(len(maps)):
+        check('cfg1 student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.6)
+    for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
+        check('cfg1 %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 5e-2)
+    # random-init network: the reference's own bf16 gradient is ~uncorrelated with the fp64 one (rel-L2 > 1, measured);
+    # the meaningful gradient statement is the trained-network test below
+    check('cfg1 gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 2.0)
+
+
+def test_tiny_bf16_20_step_trajectory_vs_reference_at_bf16():
+    """20 Adam steps (distinct batches) of the 'tiny' pair: bf16 product loss trajectory against the fp64 oracle, bounded by
+    1.5x the deviation of the reference loop run under bf16 autocast; and it trains (loss goes down)."""
+    from fpd_amd import executor as E
+    from tests.test_model_gpu import build_models
+    name, n = 'tiny', 20
+    c, gold, student, teacher = build_models(name, 'bf16')
+    B, (W, H) = c['batch'], c['image']
+    step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5, lr=2.5e-4)
+    ours = []
+    for it in range(n):
+        x, tg, tw = _cases.batch(name, it)
+        step.set_batch(x, tg, tw)
+        step.step()
+        ours.append(step.losses())
+    ours = np.array(ours)
+    t64 = _cases.traj64(name, n) if len(_cases._TRAJ.get(name, [])) >= n else None
+    if t64 is None:
+        _cases._TRAJ.pop(name, None)
+        t64 = _cases.traj64(name, n)
+    s_sd, t_sd = _cases.state_dicts(name, gold)
+    adam, ac = {}, []
+    for it in range(n):                                     # the reference loop at bf16 (CPU autocast), same Adam
+        x, tg, tw = _cases.batch(name, it)
+        with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+            tmap = hourglass_ref.hourglass_forward(t_sd, x, c['t'][1], train=False)[-1].float()
+        _, l, g = student_step(s_sd, x, tg, tw, tmap, c['s'][1], autocast='cpu')
+        fpd_ref.adam_update(s_sd, g, adam, 2.5e-4)
+        ac.append(l)
+    ac = np.array(ac)
+    d_ours = np.abs(ours - t64) / np.abs(t64)
+    d_ref = np.abs(ac - t64) / np.abs(t64)
+    for j, nm in enumerate(('pose', 'kd', 'total')):
+        check('tiny 20-step %s trajectory, max rel dev' % nm, float(d_ours[:, j].max()), float(d_ref[:, j].max()), 1e-2, 0.25)
+    assert ours[-1, 2] < ours[0, 2] and t64[-1, 2] < t64[0, 2], (ours[:, 2], t64[:, 2])
+
+
+def _pretrain(model, name, steps, seed0, lr=1e-3):
+    """Plain (non-distillation) fp32 training of `model` on synthetic targets through the product's fused step."""
+    from fpd_amd import executor as E
+    c = _cases.CONFIGS[name]
+    B, (W, H) = c['batch'], c['image']
+    step = E.FusedFPDStep(model.device_state(), model.cfg_hg, None, None, B, H, W, alpha=0.0, lr=lr)
+    for it in range(steps):
+        x, tg, tw = fpd_ref.synth_batch(seed0 + it, B, c['joints'], c['image'], c['heat'])
+        step.set_batch(x, tg, tw)
+        step.step()
+    torch.cuda.synchronize()
+    return step.losses()[0]
+
+
+def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
+    """Separates kernel error from network chaos: student and teacher of the 'tiny' pair are first
+    TRAINED (250 plain fp32 Adam steps each on synthetic targets, through the product's own fp32 step), then one FPD
+    iteration and a 20-step trajectory are evaluated in the bf16 build against the fp64 oracle: absolute bounds, and
+    never worse than 1.5x the reference at bf16."""
+    from fpd_amd import executor as E
+    from fpd_amd.lib.models import hourglass
+    from tests.test_model_gpu import build_models
+    name = 'tiny'
+    c, gold, s32, t32 = build_models(name, 'fp32')
+    t32.train()
+    l_t = _pretrain(t32, name, 250, 5000)
+    l_s = _pretrain(s32, name, 250, 7000)
+    print('pre-training: teacher loss %.4f, student loss %.4f' % (l_t, l_s))
+    s_sd = {k: v.detach().cpu().clone() for k, v in s32.state_dict().items()}
+    t_sd = {k: v.detach().cpu().clone() for k, v in t32.state_dict().items()}
+    student = hourglass.get_pose_net(_cfg(c['s'][0], c['s'][1], c['joints'], 'bf16'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(c['t'][0], c['t'][1], c['joints'], 'bf16'), is_train=False)
+    student.load_state_dict(s_sd, strict=True)
+    teacher.load_state_dict(t_sd, strict=True)
+    student, teacher = student.cuda(), teacher.cuda()
+    B, (W, H) = c['batch'], c['image']
+    x, tg, tw = _cases.batch(name, 0)
+    t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
+    with torch.no_grad():
+        tr_tmap = hourglass_ref.hourglass_forward(t64, x.double(), c['t'][1], train=False)[-1]
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            a_tmap = hourglass_ref.hourglass_forward(t_sd, x, c['t'][1], train=False)[-1].float()
+    tmap_fixed = tr_tmap.float().to(torch.bfloat16).float()
+    ours_tmap, maps, losses, grads = product_step(student, teacher, x, tg, tw, tmap_fixed, B, H, W)
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
+    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), c['s'][1])
+    a_maps, a_loss, a_grads = student_step({k: v.clone() for k, v in s_sd.items()}, x, tg, tw, tmap_fixed, c['s'][1], autocast='cpu')
+    check('trained teacher map rel-L2', rel(ours_tmap, tr_tmap), rel(a_tmap, tr_tmap), 2e-2, 0.15)
+    for i in range(len(maps)):
+        check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.15)
+    for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
+        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 2e-2)
+    check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 0.8)
+
+
+@pytest.fixture(scope='module')
+def full():
+    """Full benchmark size: synthetic checkpoints, calibrated teacher, one batch, the fixed KD target (the torch-fp32 teacher
+    map rounded to bf16), and the fp64 referee for the student step / two teacher samples."""
+    dev = torch.device('cuda', 0)
+    B, J, H, W = 32, 16, 256, 256
+    s_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(128, 4, J), 1)
+    t_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(256, 8, J), 2)
+    x, tg, tw = fpd_ref.synth_batch(100, B, J, (W, H), (W // 4, H // 4))
+    t_cu = {k: v.to(dev) for k, v in t_sd.items()}
+    with torch.no_grad():
+        fpd_ref.calibrate_bn(t_cu, 8, [fpd_ref.synth_batch(200 + i, 8, J, (W, H), (W // 4, H // 4))[0].to(dev) for i in range(2)])
+        m_tmap = hourglass_ref.hourglass_forward(t_cu, x.to(dev), 8, train=False)[-1].cpu()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            a_tmap = hourglass_ref.hourglass_forward(t_cu, x.to(dev), 8, train=False)[-1].float().cpu()
+    t_sd = {k: v.cpu() for k, v in t_cu.items()}
+    tmap_fixed = m_tmap.to(torch.bfloat16).float()
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
+    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), 4)
+    t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in t_sd.items()}
+    with torch.no_grad():
+        t_tmap2 = hourglass_ref.hourglass_forward(t64, x[:2].double(), 8, train=False)[-1]          # eval BN: per-sample
+    return AD(dev=dev, B=B, J=J, H=H, W=W, s_sd=s_sd, t_sd=t_sd, x=x, tg=tg, tw=tw, m_tmap=m_tmap, a_tmap=a_tmap,
+              tmap_fixed=tmap_fixed, t_maps=t_maps, t_loss=t_loss, t_grads=t_grads, t_tmap2=t_tmap2)
+
+
+def test_full_size_bf16_step_vs_reference_at_bf16(full):
+    """B=32, 256x256, hg4x128 <- hg8x256 -- the exact build and shapes bench.py times.  reference-at-bf16 = the oracle on
+    CUDA under torch.autocast(bfloat16) (MIOpen bf16 convolutions, an implementation independent of this package)."""
+    from fpd_amd.lib.models import hourglass
+    f = full
+    student = hourglass.get_pose_net(_cfg(128, 4, f.J, 'bf16'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(256, 8, f.J, 'bf16'), is_train=False)
+    student.load_state_dict(f.s_sd, strict=True)
+    teacher.load_state_dict(f.t_sd, strict=True)
+    student, teacher = student.to(f.dev), teacher.to(f.dev)
+    ours_tmap, maps, losses, grads = product_step(student, teacher, f.x, f.tg, f.tw, f.tmap_fixed, f.B, f.H, f.W)
+    s_cu = {k: v.to(f.dev) for k, v in f.s_sd.items()}
+    a_maps, a_loss, a_grads = student_step(s_cu, f.x.to(f.dev), f.tg.to(f.dev), f.tw.to(f.dev), f.tmap_fixed.to(f.dev), 4, autocast='cuda')
+    torch.cuda.synchronize()
+    check('full teacher map rel-L2 (2 samples)', rel(ours_tmap[:2], f.t_tmap2), rel(f.a_tmap[:2], f.t_tmap2), 2e-2, 0.8)
+    for i in range(4):
+        check('full student map %d rel-L2' % i, rel(maps[i], f.t_maps[i]), rel(a_maps[i], f.t_maps[i]), 2e-2, 0.8)
+    for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, f.t_loss):
+        check('full %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 5e-2)
+    check('full gradient rel-L2', grads_rel(grads, f.t_grads), grads_rel({k: v.cpu() for k, v in a_grads.items()}, f.t_grads), 5e-2, 2.0)

@@ -61,6 +61,9 @@ class Bench:
         return self
 
     def run(self, ops, backend, partials=False):
+        if partials:                         # slab reduction of all weight gradients of the list (one gradient bucket)
+            wg = [o for o in ops if o.kind == 'wgrad']
+            ops = list(ops) + [G.Op('wreduce', bucket=0, wgrads=wg, bufs=[x for w in wg for x in (w.dw, w.dbias) if x is not None])]
         PI.run(self.cpu, ops)
         low = E.Lowering(self.gpu, self.dtype)
         plan = R.Plan()
@@ -72,11 +75,9 @@ class Bench:
                 lowered.append(low.wprep([(e['w'], e.get('w_fwd'), e.get('w_bwd')) for e in op.entries]))
             else:
                 lowered.append(low.op(op))
-        red = low.finish_partials()
+        low.finish_partials()
         for code, st in lowered:
             plan.add(code, st)
-        if red is not None:
-            plan.add(*red)
         self.n_partial_ops = len(low.partials)
         R.set_backend(prev)
         prev = R.set_backend(backend)
