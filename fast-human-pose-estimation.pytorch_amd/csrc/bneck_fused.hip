@@ -72,10 +72,15 @@ __global__ void bneck_fold_kernel(const fpd_bneck_t a, float* out) { bneck_fold_
 // Block bid_in of the nblk blocks assigned to fused Bottleneck `a`: persistent over its ntiles 128-pixel tiles
 // (tile = bid_in, bid_in + nblk, ...).  A grid smaller than the CU count leaves compute units free for the
 // latency-bound student kernels that run concurrently on another stream (a resident block owns its CU's LDS).
-template <int P>
+// DMA: the [P][P] weight tiles of phases B/C go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no
+// ds_write pass): ring rows are unpadded (the DMA destination is lane-linear, 1 KiB per wave instruction) and bank
+// conflicts are avoided by an XOR swizzle of the 16-byte chunks applied on the per-lane SOURCE address and again on
+// the fragment reads (chunk c of row r sits at position c ^ sw(r)).
+template <int P, bool DMA>
 __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int logW, const int swz, const int bid_in,
                                                 const int nblk, const int ntiles) {
     constexpr int C = 2 * P;
+    constexpr int LDW = DMA ? P : P + 8;        // weight-ring row stride (bf16 elements)
     constexpr int LDX = 64 + 8;                 // phase-A staging rows (bf16 elements)
     constexpr int LD2 = P + 8;                  // a2 / a3 rows and [P][P] weight-tile rows
     constexpr int TNH = P / 64;                 // 32-channel MFMA tiles per wave (a wave owns half of a P-wide tile)
@@ -190,22 +195,60 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         t3o[i] = row * P + col;
         tlo[i] = row * LD2 + col;
     }
-    u32x4 rb[2][WV];
+    u32x4 rb[DMA ? 1 : 2][DMA ? 1 : WV];
     auto t_load = [&](auto sc_) __attribute__((always_inline)) {
         constexpr int s = decltype(sc_)::value;
-        static_for<WV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const bf16_t* src = s < 9 ? w2 + (t2o[i] + s * P) : w3 + (t3o[i] + (s - 9) * P * P);
-            rb[s & 1][i] = *reinterpret_cast<const u32x4*>(src);
-        });
+        if constexpr (!DMA) {
+            static_for<WV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const bf16_t* src = s < 9 ? w2 + (t2o[i] + s * P) : w3 + (t3o[i] + (s - 9) * P * P);
+                rb[s & 1][i] = *reinterpret_cast<const u32x4*>(src);
+            });
+        }
     };
     auto t_store = [&](auto sc_) __attribute__((always_inline)) {
         constexpr int s = decltype(sc_)::value;
-        bf16_t* dst = sR2 + (s & 1) * P * LD2;
-        static_for<WV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            *reinterpret_cast<u32x4*>(dst + tlo[i]) = rb[s & 1][i];
-        });
+        if constexpr (!DMA) {
+            bf16_t* dst = sR2 + (s & 1) * P * LDW;
+            static_for<WV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                *reinterpret_cast<u32x4*>(dst + tlo[i]) = rb[s & 1][i];
+            });
+        }
+    };
+    // LDS-DMA of weight tile s into ring buffer s & 1: P rows of 2P bytes = P*P*2/1024 wave instructions, 8 waves.
+    // Wave instruction q covers ring bytes [q*1024, q*1024 + 1024): rows q*RPI .. +RPI, lane L -> row q*RPI + L/CPR,
+    // position L % CPR, fetching global chunk (position ^ sw(row)) of that row.
+    constexpr int CPR = P / 8;                  // 16-byte chunks per weight row
+    constexpr int RPI = 64 / CPR;               // rows per wave instruction
+    constexpr int DPW = P / RPI / 8;            // wave instructions per wave per tile
+    // per-lane byte offsets of the DPW pieces this wave fetches of a tile, for the w2 ([P][9][P]) and w3 ([C][P]) row pitches;
+    // the step's constant part (s*P resp. (s-9)*P*P elements) is added at issue time
+    unsigned dma2[DMA ? DPW : 1], dma3[DMA ? DPW : 1];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int row = wave * DPW * RPI + j * RPI + lane / CPR;
+            const int sw = (P == 128) ? (row & 15) : ((row >> 1) & 7);      // sw(row): 16 consecutive rows -> 16 slots
+            const int c8 = ((lane % CPR) ^ sw) * 8;
+            dma2[j] = (unsigned)(row * 9 * P + c8) * 2u;
+            dma3[j] = (unsigned)(row * P + c8) * 2u;
+        }
+    }
+    auto t_dma = [&](auto sc_) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc_)::value;
+        if constexpr (DMA) {
+            unsigned char* ring = reinterpret_cast<unsigned char*>(sR2) + (s & 1) * P * P * 2 + wave * DPW * 1024;
+            const char* gbase = s < 9 ? reinterpret_cast<const char*>(w2) + s * P * 2
+                                      : reinterpret_cast<const char*>(w3) + (s - 9) * P * P * 2;
+            static_for<DPW>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                unsigned off = s < 9 ? dma2[j] : dma3[j];
+                asm volatile("" : "+v"(off));    // keep the 44 (step, piece) addresses from being hoisted out of the tile loop
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
+                                                 (__attribute__((address_space(3))) void*)(ring + j * 1024), 16, 0, 0);
+            });
+        }
     };
 
     // ---- tables (once per block): folded by the host-side prep pass (a.folded) or here ----
@@ -283,6 +326,10 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             }
             __syncthreads();
         });
+        if (p + 1 == npass) {                    // both staging buffers are dead: the first two weight tiles of phase B
+            t_dma(std::integral_constant<int, 0>{});     // travel while the a2 image is written out
+            t_dma(std::integral_constant<int, 1>{});
+        }
         // a2 = relu(bn2(conv1 + b1)) as bf16; rows of the zero-column layout.  Halo pixels outside the tensor hold
         // junk that no lane reads (their readers are redirected to the zero pixels).
         const int hp = hp0 + 128 * p + q * 32 + (lane & 31);
@@ -320,7 +367,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     // (the last barrier of phase A already separates its staging reads from the tile stores below)
     t_store(std::integral_constant<int, 0>{});
     t_load(std::integral_constant<int, 2>{});
-    __syncthreads();                             // tile 0 + the whole a2 image visible
+    __syncthreads();                             // tile 0 (+ tile 1 when DMA) + the whole a2 image visible
     STAMP(3);
 
     f32x16 accB[TNH], accC[2][TNH];
@@ -329,14 +376,16 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
 #pragma unroll
         for (int i = 0; i < 16; ++i) accB[tn][i] = 0.f;
 
+    const int wsw = (P == 128) ? (lane & 15) : ((lane >> 1) & 7);     // sw(row) of this lane's weight rows (DMA layout)
     auto mma = [&](const bf16_t* arow, int buf, f32x16* acc) __attribute__((always_inline)) {
-        const bf16_t* wrow = sR2 + buf * P * LD2 + (hC * CW + (lane & 31)) * LD2 + koff;
+        const bf16_t* wbase = sR2 + buf * P * LDW + (hC * CW + (lane & 31)) * LDW;
 #pragma unroll
         for (int kk = 0; kk < P / 16; ++kk) {
             const bf16x8 px = *reinterpret_cast<const bf16x8*>(arow + kk * 16);
+            const int wo = DMA ? (((2 * kk + (lane >> 5)) ^ wsw) * 8) : (kk * 16 + koff);
 #pragma unroll
             for (int tn = 0; tn < TNH; ++tn) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + tn * 32 * LD2 + kk * 16);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wbase + tn * 32 * LDW + wo);
                 acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, px, acc[tn], 0, 0, 0);
             }
         }
@@ -361,6 +410,9 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
 
     static_for<NSTEP>([&](auto sc_) {
         constexpr int s = decltype(sc_)::value;
+        // DMA: tile s+1 goes into the buffer tile s-1 left (every wave is past step s-1's barrier); tiles 0/1 were issued
+        // at the end of phase A.  The barrier closing this step drains it (hipcc emits vmcnt(0) in front of s_barrier).
+        if constexpr (DMA && s >= 1 && s + 1 < NSTEP) t_dma(std::integral_constant<int, (s + 1 < NSTEP ? s + 1 : 0)>{});
         if constexpr (s < 9) {
             mma(sA2 + ab[s / 3] + (s % 3) * LD2 + koff, s & 1, accB);
         } else {
@@ -448,18 +500,25 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
 #endif
 }
 
-template <int P>
+template <int P, bool DMA>
 __global__ __launch_bounds__(512, 1) void bneck_eval_kernel(const fpd_bneck_t a, const int logW, const int ntiles) {
-    bneck_eval_body<P>(a, logW, (ntiles & 7) == 0, blockIdx.x, gridDim.x, ntiles);
+    bneck_eval_body<P, DMA>(a, logW, (ntiles & 7) == 0, blockIdx.x, gridDim.x, ntiles);
 }
 
 // Two independent fused Bottlenecks (the up-branch and the low-branch one of an hourglass level) in one launch.
-template <int P>
+template <int P, bool DMA>
 __global__ __launch_bounds__(512, 1) void bneck_eval_pair_kernel(const fpd_bneck_t a, const fpd_bneck_t b, const int logWa,
                                                                  const int logWb, const int nblk_a, const int ntiles_a,
                                                                  const int ntiles_b) {
-    if ((int)blockIdx.x < nblk_a) bneck_eval_body<P>(a, logWa, (ntiles_a & 7) == 0, blockIdx.x, nblk_a, ntiles_a);
-    else bneck_eval_body<P>(b, logWb, (ntiles_b & 7) == 0, (int)blockIdx.x - nblk_a, (int)gridDim.x - nblk_a, ntiles_b);
+    if ((int)blockIdx.x < nblk_a) bneck_eval_body<P, DMA>(a, logWa, (ntiles_a & 7) == 0, blockIdx.x, nblk_a, ntiles_a);
+    else bneck_eval_body<P, DMA>(b, logWb, (ntiles_b & 7) == 0, (int)blockIdx.x - nblk_a, (int)gridDim.x - nblk_a, ntiles_b);
+}
+
+// FPD_BNECK_DMA=0|1: weight tiles through registers (round 1) or by LDS-DMA
+static bool bneck_use_dma() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_BNECK_DMA"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
 }
 
 // grid cap of the persistent kernel (FPD_BNECK_BLOCKS): below the CU count so that concurrently running streams find
@@ -490,12 +549,12 @@ size_t bneck_lds_bytes(int W) {
     return (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
 }
 
-template <int P>
+template <int P, bool DMA>
 int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
     const size_t lds = std::max(bneck_lds_bytes<P>(a.W), bneck_lds_bytes<P>(b.W));
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P, DMA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
@@ -511,11 +570,11 @@ int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st
         nb = bneck_blocks(tb, capb);
         na = bneck_blocks(ta, std::max(1, cap - nb));
     }
-    hipLaunchKernelGGL((bneck_eval_pair_kernel<P>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, ta, tb);
+    hipLaunchKernelGGL((bneck_eval_pair_kernel<P, DMA>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, ta, tb);
     return 0;
 }
 
-template <int P>
+template <int P, bool DMA>
 int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
     constexpr int C = 2 * P, LD2 = P + 8, LDX = 72, CW = 32 * (P / 64);
     const int hrows = (128 >> logW) + 2, WP = a.W + 2;
@@ -523,13 +582,13 @@ int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
     const size_t lds = (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_kernel<P>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_kernel<P, DMA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
     const int ntiles = cdiv(a.N * a.H * a.W, 128);
-    hipLaunchKernelGGL((bneck_eval_kernel<P>), dim3(bneck_blocks(ntiles, bneck_block_cap())), dim3(512), lds, st, a, logW, ntiles);
+    hipLaunchKernelGGL((bneck_eval_kernel<P, DMA>), dim3(bneck_blocks(ntiles, bneck_block_cap())), dim3(512), lds, st, a, logW, ntiles);
     return 0;
 }
 
@@ -547,13 +606,15 @@ int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st) {
     if (!bneck_in_domain(a)) return 1;
     int logW = 0;
     while ((1 << logW) < a.W) ++logW;
-    return a.P == 128 ? launch_bneck<128>(a, logW, st) : launch_bneck<64>(a, logW, st);
+    if (bneck_use_dma()) return a.P == 128 ? launch_bneck<128, true>(a, logW, st) : launch_bneck<64, true>(a, logW, st);
+    return a.P == 128 ? launch_bneck<128, false>(a, logW, st) : launch_bneck<64, false>(a, logW, st);
 }
 
 // 0 = both launched as one kernel, 1 = not pairable (caller launches them one by one)
 int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
     if (!bneck_in_domain(a) || !bneck_in_domain(b) || a.P != b.P) return 1;
-    return a.P == 128 ? launch_bneck_pair<128>(a, b, st) : launch_bneck_pair<64>(a, b, st);
+    if (bneck_use_dma()) return a.P == 128 ? launch_bneck_pair<128, true>(a, b, st) : launch_bneck_pair<64, true>(a, b, st);
+    return a.P == 128 ? launch_bneck_pair<128, false>(a, b, st) : launch_bneck_pair<64, false>(a, b, st);
 }
 
 // folded tables ([3C + 4P] floats) for a.folded; 1 = P not supported

@@ -66,8 +66,8 @@ def traj64(name, steps=3):
     """fp64 oracle loss trajectory [[pose, kd, loss]] over `steps` Adam steps.  Adam's first update is
     lr*sign(g), so sign flips of noise-level gradients make fp32 trajectories diverge: measured here, the
     reference's own fp32 trajectory is 1.3e-3..1.5e-3 away from this one at steps 2-3 of 'tiny'."""
-    if name in _TRAJ:
-        return _TRAJ[name]
+    if name in _TRAJ and len(_TRAJ[name]) >= steps:
+        return _TRAJ[name][:steps]
     import numpy as np
     c = CONFIGS[name]
     s_sd, t_sd = state_dicts(name)

@@ -83,30 +83,38 @@ def test_fpd_train_follows_the_golden_adam_trajectory_and_feeds_meters_every_ite
 
 
 def test_pipelined_loop_equals_unpipelined_steps_and_lr_schedule_reaches_the_device():
-    """fpd_train's loop (teacher one batch ahead, two-slot staged teacher map, deferred readback) against plain
-    un-pipelined FusedFPDStep.step() calls on distinct batches: identical parameters after 4 iterations (fp32: bitwise
-    up to the atomics' summation order -> 1e-6 relative).  A changed param_groups lr reaches the Adam kernel."""
+    """fpd_train's loop (teacher one batch ahead on its own stream, two-slot staged teacher map, deferred readback) against
+    plain un-pipelined FusedFPDStep.step() calls on 6 DISTINCT batches: the per-iteration pose / KD losses agree to 2e-3
+    relative (a stale or wrong-slot teacher map would move the KD term by tens of percent; what remains is Adam turning
+    noise-level gradients -- fp32 atomics order -- into +-lr updates).  A changed param_groups lr reaches the Adam kernel."""
     from fpd_amd import executor as E
     from fpd_amd.lib.core import function as F
     from fpd_amd.lib.core.loss import JointsMSELoss
     from fpd_amd.lib.utils.utils import FusedAdam
-    n = 4
+    n = 6
     loader = _Loader('tiny', n, same_batch=False)
     c, gold, s1, t1 = _models('tiny')
-    opt = FusedAdam(s1, lr=1e-3)
+    opt = FusedAdam(s1, lr=2.5e-4)
     crit = JointsMSELoss(True).cuda()
     F.fpd_train(_cfgnode(print_freq=100), loader, s1, t1, crit, crit, opt, 0, '/tmp', '/tmp', None)
+    st1 = F.fused_step_for(s1, t1, opt, _cases.batch('tiny', 0)[0].shape, 0.5, 1, (True, True))
+    pipelined = st1.metric.log.view(-1, 4)[:n, 2:4].cpu().numpy()
     _, _, s2, t2 = _models('tiny')
     step = E.FusedFPDStep(s2.device_state(), s2.cfg_hg, t2.device_state(), t2.cfg_hg, c['batch'], c['image'][1], c['image'][0],
-                          alpha=0.5, lr=1e-3)
+                          alpha=0.5, lr=2.5e-4)
+    plain = []
     for x, tg, tw, _ in loader:
         step.set_batch(x, tg, tw)
         step.step()
-    torch.cuda.synchronize()
+        plain.append(step.losses()[:2])
+    plain = np.array(plain)
+    dev = np.abs(pipelined - plain) / np.abs(plain)
+    assert dev.max() < 2e-3, (dev, pipelined, plain)
+    assert np.abs(plain[1:, 1] - plain[:-1, 1]).min() > 1e-3 * plain[:, 1].mean()      # the batches really differ in their KD term
     p1, p2 = s1._flat['param'], s2._flat['param']
-    rel = float((p1 - p2).norm() / p2.norm())
-    assert rel < 1e-6, rel
-    # lr: halve it through param_groups (what MultiStepLR / tools/fpd_train.py write) and run one more epoch
+    assert float((p1 - p2).norm() / p2.norm()) < 2e-2
+    # lr: zero it through param_groups (what the LR schedule / tools/fpd_train.py write) and run one more epoch
+    torch.cuda.synchronize()
     before = p1.clone()
     opt.param_groups[0]['lr'] = 0.0
     F.fpd_train(_cfgnode(print_freq=100), _Loader('tiny', 1), s1, t1, crit, crit, opt, 1, '/tmp', '/tmp', None)
@@ -189,14 +197,17 @@ def test_tools_fpd_train_cli_smoke_and_auto_resume(tmp_path):
     cfgd = os.path.join(ROOT, 'experiments', 'fpd_synthetic')
     base = [sys.executable, os.path.join(ROOT, 'tools', 'fpd_train.py'), '--cfg', os.path.join(cfgd, 'hg4x128_student.yaml'),
             '--tcfg', os.path.join(cfgd, 'hg8x256_teacher.yaml'), '--max-iters', '3',
-            'OUTPUT_DIR', str(tmp_path), 'MODEL.EXTRA.NUM_FEATURES', '32', 'MODEL.EXTRA.NUM_STACKS', '2', 'MODEL.IMAGE_SIZE', '64,64',
-            'MODEL.HEATMAP_SIZE', '16,16', 'TRAIN.BATCH_SIZE_PER_GPU', '4', 'DATASET.NUM_SAMPLES', '32', 'PRINT_FREQ', '1',
+            'OUTPUT_DIR', str(tmp_path), 'MODEL.EXTRA.NUM_FEATURES', '32', 'MODEL.EXTRA.NUM_STACKS', '2', 'MODEL.IMAGE_SIZE', '128,128',
+            'MODEL.HEATMAP_SIZE', '32,32', 'TRAIN.BATCH_SIZE_PER_GPU', '4', 'DATASET.NUM_SAMPLES', '32', 'PRINT_FREQ', '1',
             'TRAIN.LR_STEP', '[2,3]', 'AUTO_RESUME', 'True', 'MODEL.DTYPE', 'fp32']
     env = dict(os.environ, PYTHONPATH=ROOT)
     r = subprocess.run(base + ['TRAIN.END_EPOCH', '2'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     log = r.stdout + r.stderr
-    assert 'Total Parameters' in log and log.count('POSE_Loss') == 6 and 'epoch 1 done' in log
+    assert 'Total Parameters' in log and log.count('\tPOSE_Loss') == 6 and 'epoch 1 done' in log
+    import re
+    last = [float(m) for m in re.findall(r'last logged loss ([0-9.eE+-]+)', log)]
+    assert len(last) == 2 and all(0 < v < 10 for v in last), last                     # it trains on finite, sane losses
     ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == 'checkpoint.pth']
     assert len(ckpts) == 1
     ck = torch.load(ckpts[0], map_location='cpu', weights_only=False)

@@ -4,7 +4,9 @@ The CPU oracle needs ~20 s per step at this size, so the checker here is the SAM
 oracle/fpd_ref.py -- the restatement pinned against the reference's golden vectors by tests/test_oracle_golden.py) executed
 on CUDA tensors: plain torch fp32 ops (MIOpen convolutions, torch batch_norm, autograd), an implementation independent of
 this package's kernels.  The product side is the fp32 parity build of the fused step, driven through the C ABI.
-The referee is the oracle in fp64 on the CPU (student step: ~40 s; teacher: two samples, eval BN is per-sample).  Criterion as in
+The referee is the oracle in fp64 on the CPU (student step: ~40 s; teacher: two samples, eval BN is per-sample), computed
+once per module and shared by the fp32 test and the bf16 (benchmark build) test; every student step -- ours, MIOpen's,
+the referee's -- distils from the SAME teacher map (torch's fp32 map rounded to bf16, injected into the staging slot).  Criterion as in
 tests/_cases.assert_parity: at this depth fp32 rounding is amplified to ~4e-4 on the O(1) teacher map and to percents on
 early-layer gradients, for MIOpen as for us -- we must never be less accurate than 1.5x the torch fp32 evaluation.
 """
@@ -13,6 +15,7 @@ import pytest
 import torch
 
 from oracle import fpd_ref, hourglass_ref
+from tests.test_bf16_parity_gpu import check, grads_rel, product_step, rel, student_step
 
 pytestmark = pytest.mark.gpu
 
@@ -25,62 +28,48 @@ def _cfg(feats, stacks, joints, dtype):
     return AD(MODEL=AD(NUM_JOINTS=joints, DTYPE=dtype, EXTRA=AD(NUM_FEATURES=feats, NUM_STACKS=stacks, NUM_BLOCKS=1)))
 
 
-def test_full_size_fpd_step_matches_the_oracle_run_on_cuda():
-    from fpd_amd import executor as E
-    from fpd_amd.lib.models import hourglass
+@pytest.fixture(scope='module')
+def full():
+    """Full benchmark size: synthetic checkpoints, calibrated teacher, one batch, the fixed KD target (the torch-fp32 teacher
+    map rounded to bf16), and the fp64 referee for the student step / two teacher samples."""
     dev = torch.device('cuda', 0)
     B, J, H, W = 32, 16, 256, 256
-    s_keys, t_keys = hourglass_ref.hourglass_keys(128, 4, J), hourglass_ref.hourglass_keys(256, 8, J)
-    s_sd, t_sd = fpd_ref.synth_state_dict(s_keys, 1), fpd_ref.synth_state_dict(t_keys, 2)
+    s_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(128, 4, J), 1)
+    t_sd = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(256, 8, J), 2)
     x, tg, tw = fpd_ref.synth_batch(100, B, J, (W, H), (W // 4, H // 4))
-    # give the random teacher sane eval statistics (same procedure as the golden generator), on the GPU
     t_cu = {k: v.to(dev) for k, v in t_sd.items()}
     with torch.no_grad():
         fpd_ref.calibrate_bn(t_cu, 8, [fpd_ref.synth_batch(200 + i, 8, J, (W, H), (W // 4, H // 4))[0].to(dev) for i in range(2)])
-    t_sd = {k: v.cpu() for k, v in t_cu.items()}
-
-    student = hourglass.get_pose_net(_cfg(128, 4, J, 'fp32'), is_train=True)
-    teacher = hourglass.get_pose_net(_cfg(256, 8, J, 'fp32'), is_train=False)
-    student.load_state_dict(s_sd, strict=True)
-    teacher.load_state_dict(t_sd, strict=True)
-    student, teacher = student.to(dev), teacher.to(dev)
-    step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5)
-    step.set_batch(x, tg, tw)
-    step.teacher_async(x)
-    # run the phases by hand so that the gradients can be read before Adam consumes them
-    s = step.student
-    torch.cuda.current_stream().wait_event(step.ev_t[0])
-    s.run('prep'); s.run('fwd'); s.run('mid'); s.run('bwd')
-    torch.cuda.synchronize()
-    ours_maps = [s.output_view(i).permute(0, 3, 1, 2).float().cpu() for i in range(4)]
-    ours_tmap = step.tmap[0].view(B, H // 4, W // 4, J).permute(0, 3, 1, 2).float().cpu()
-    pose, kd, loss = step.losses()
-    student._attach_grads()
-    ours_grads = {k: p.grad.detach().cpu() for k, p in student.named_parameters()}
-
-    # ---- checker 1: the oracle on CUDA (torch fp32 / MIOpen), student step against the SAME teacher map ----
-    tmap_fixed = ours_tmap.clone()
-
-    def student_step(sd, xin, tgt, wgt, tmap):
-        names = fpd_ref.param_names(sd)
-        for k in names:
-            sd[k].requires_grad_(True)
-        outs = hourglass_ref.hourglass_forward(sd, xin, 4, train=True)
-        pose_, kd_, loss_ = fpd_ref.fpd_losses(outs, tmap, tgt, wgt, 0.5)
-        loss_.backward()
-        return [o.detach() for o in outs], (float(pose_), float(kd_), float(loss_)), {k: sd[k].grad.detach() for k in names}
-
-    s_cu = {k: v.to(dev) for k, v in s_sd.items()}
-    m_maps, m_loss, m_grads = student_step(s_cu, x.to(dev), tg.to(dev), tw.to(dev), tmap_fixed.to(dev))
-    with torch.no_grad():
         m_tmap = hourglass_ref.hourglass_forward(t_cu, x.to(dev), 8, train=False)[-1].cpu()
-    torch.cuda.synchronize()
-    # ---- checker 2 (referee): the oracle in fp64 on the CPU ----
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            a_tmap = hourglass_ref.hourglass_forward(t_cu, x.to(dev), 8, train=False)[-1].float().cpu()
+    t_sd = {k: v.cpu() for k, v in t_cu.items()}
+    tmap_fixed = m_tmap.to(torch.bfloat16).float()
     s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
-    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double())
+    t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), 4)
     t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in t_sd.items()}
     with torch.no_grad():
-        t_tmap2 = hourglass_ref.hourglass_forward(t64, x[:2].double(), 8, train=False)[-1]    # eval BN: per-sample
+        t_tmap2 = hourglass_ref.hourglass_forward(t64, x[:2].double(), 8, train=False)[-1]          # eval BN: per-sample
+    return AD(dev=dev, B=B, J=J, H=H, W=W, s_sd=s_sd, t_sd=t_sd, x=x, tg=tg, tw=tw, m_tmap=m_tmap, a_tmap=a_tmap,
+              tmap_fixed=tmap_fixed, t_maps=t_maps, t_loss=t_loss, t_grads=t_grads, t_tmap2=t_tmap2)
+
+
+def test_full_size_fpd_step_matches_the_oracle_run_on_cuda(full):
+    """fp32 parity build at full size: checker = the oracle on CUDA (torch fp32 / MIOpen), referee = the oracle in fp64."""
+    from fpd_amd.lib.models import hourglass
+    from tests.test_bf16_parity_gpu import product_step
+    f = full
+    student = hourglass.get_pose_net(_cfg(128, 4, f.J, 'fp32'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(256, 8, f.J, 'fp32'), is_train=False)
+    student.load_state_dict(f.s_sd, strict=True)
+    teacher.load_state_dict(f.t_sd, strict=True)
+    student, teacher = student.to(f.dev), teacher.to(f.dev)
+    ours_tmap, ours_maps, (pose, kd, loss), ours_grads = product_step(student, teacher, f.x, f.tg, f.tw, f.tmap_fixed, f.B, f.H, f.W)
+    # ---- checker 1: the oracle on CUDA (torch fp32 / MIOpen), student step against the SAME teacher map ----
+    s_cu = {k: v.to(f.dev) for k, v in f.s_sd.items()}
+    m_maps, m_loss, m_grads = student_step(s_cu, f.x.to(f.dev), f.tg.to(f.dev), f.tw.to(f.dev), f.tmap_fixed.to(f.dev), 4)
+    torch.cuda.synchronize()
+    m_tmap, t_tmap2, t_maps, t_loss, t_grads = f.m_tmap, f.t_tmap2, f.t_maps, f.t_loss, f.t_grads
 
     def err(a, b):
         return float((a.double().cpu() - b.double().cpu()).abs().max())
@@ -94,11 +83,7 @@ def test_full_size_fpd_step_matches_the_oracle_run_on_cuda():
         assert e_ours <= max(1e-4, 1.5 * e_ref), ('student map %d' % i, e_ours, e_ref)
     assert max(abs(a - b) for a, b in zip((pose, kd, loss), t_loss)) < 1e-5, ((pose, kd, loss), t_loss)
     # gradients against the fp64 truth: whole-vector relative L2, and per tensor relative to the tensor's own scale
-    def rel_l2(g):
-        num = sum(float(((g[k].double().cpu() - t_grads[k]) ** 2).sum()) for k in t_grads)
-        den = sum(float((t_grads[k] ** 2).sum()) for k in t_grads)
-        return (num / den) ** 0.5
-    r_ours, r_ref = rel_l2(ours_grads), rel_l2(m_grads)
+    r_ours, r_ref = grads_rel(ours_grads, t_grads), grads_rel(m_grads, t_grads)
     assert r_ours <= max(2e-3, 1.5 * r_ref), ('gradient rel. L2 vs fp64', r_ours, r_ref)
     gmax = max(float(v.abs().max()) for v in t_grads.values())
     for k, tgrad in t_grads.items():
@@ -109,6 +94,28 @@ def test_full_size_fpd_step_matches_the_oracle_run_on_cuda():
         assert e_o <= max(5.0 * e_r, 0.2 * scale), (k, e_o, e_r, scale)
     print('full size: teacher |ours-fp64| %.2e (miopen %.2e); grads rel-L2 ours %.2e miopen %.2e' % (
         err(ours_tmap[:2], t_tmap2), err(m_tmap[:2], t_tmap2), r_ours, r_ref))
+
+
+def test_full_size_bf16_step_vs_reference_at_bf16(full):
+    """B=32, 256x256, hg4x128 <- hg8x256 -- the exact build and shapes bench.py times.  reference-at-bf16 = the oracle on
+    CUDA under torch.autocast(bfloat16) (MIOpen bf16 convolutions, an implementation independent of this package)."""
+    from fpd_amd.lib.models import hourglass
+    f = full
+    student = hourglass.get_pose_net(_cfg(128, 4, f.J, 'bf16'), is_train=True)
+    teacher = hourglass.get_pose_net(_cfg(256, 8, f.J, 'bf16'), is_train=False)
+    student.load_state_dict(f.s_sd, strict=True)
+    teacher.load_state_dict(f.t_sd, strict=True)
+    student, teacher = student.to(f.dev), teacher.to(f.dev)
+    ours_tmap, maps, losses, grads = product_step(student, teacher, f.x, f.tg, f.tw, f.tmap_fixed, f.B, f.H, f.W)
+    s_cu = {k: v.to(f.dev) for k, v in f.s_sd.items()}
+    a_maps, a_loss, a_grads = student_step(s_cu, f.x.to(f.dev), f.tg.to(f.dev), f.tw.to(f.dev), f.tmap_fixed.to(f.dev), 4, autocast='cuda')
+    torch.cuda.synchronize()
+    check('full teacher map rel-L2 (2 samples)', rel(ours_tmap[:2], f.t_tmap2), rel(f.a_tmap[:2], f.t_tmap2), 2e-2, 0.8)
+    for i in range(4):
+        check('full student map %d rel-L2' % i, rel(maps[i], f.t_maps[i]), rel(a_maps[i], f.t_maps[i]), 2e-2, 0.8)
+    for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, f.t_loss):
+        check('full %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 5e-2)
+    check('full gradient rel-L2', grads_rel(grads, f.t_grads), grads_rel({k: v.cpu() for k, v in a_grads.items()}, f.t_grads), 5e-2, 2.0)
 
 
 def _bf16_models(dev):

@@ -21,7 +21,12 @@ SHAPES = [
     ('t 3x3 128>128 @8', 32, 8, 8, 128, 128, 3, 1, 'eval', False),
     ('t 3x3 128>128 @4', 32, 4, 4, 128, 128, 3, 1, 'eval', False),
     ('t 1x1 256>128 @4', 32, 4, 4, 256, 128, 1, 0, 'eval', False),
+    ('s 3x3 64>64 @32', 32, 32, 32, 64, 64, 3, 1, 'train', False),
+    ('s 3x3 64>64 @16', 32, 16, 16, 64, 64, 3, 1, 'train', False),
     ('s 3x3 64>64 @8', 32, 8, 8, 64, 64, 3, 1, 'train', False),
+    ('s 3x3 64>64 @4', 32, 4, 4, 64, 64, 3, 1, 'train', False),
+    ('s 1x1 128>64 @8', 32, 8, 8, 128, 64, 1, 0, 'train', False),
+    ('s 1x1 64>128 @8', 32, 8, 8, 64, 128, 1, 0, 'train', True),
     ('l1 3x3 32>32 @128', 32, 128, 128, 32, 32, 3, 1, 'train', False),
 ]
 
