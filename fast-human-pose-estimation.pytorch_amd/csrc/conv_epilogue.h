@@ -195,6 +195,41 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     }
     if (want_stats) {
         double s1[VEC], s2[VEC];
+        if constexpr (sizeof(T) == 2) {
+            // bf16 build: the lanes of a wave that own the same channel vector are combined in fp32 first (shuffles of
+            // 32-bit values, no per-lane fp64 arithmetic); fp64 starts at the per-wave partial.  The forward statistics use
+            // a shift that is COMMON to those lanes -- lane cv's first value, broadcast -- so the shifted fp32 sums of the
+            // <= 64 rows a wave covers carry no cancellation; un-shifting happens once, in fp64.
+            float cs[VEC];
+            float nr = (float)nrow;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) cs[e] = bwd ? 0.f : __shfl(cshift[e], lane % CVN, 64);
+            if (!bwd) {
+                // re-base this lane's sums from its own shift to the common one: sum (v-cs) = f1 + n d, sum (v-cs)^2 =
+                // f2 + 2 d f1 + n d^2 with d = c - cs (small: both are values of the same channel)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float d = cshift[e] - cs[e];
+                    f2[e] = f2[e] + 2.f * d * f1[e] + nr * d * d;
+                    f1[e] = f1[e] + nr * d;
+                }
+            }
+#pragma unroll
+            for (int o = CVN; o < 64; o <<= 1) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    f1[e] += __shfl_xor(f1[e], o, 64);
+                    f2[e] += __shfl_xor(f2[e], o, 64);
+                }
+                nr += __shfl_xor(nr, o, 64);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double c = (double)cs[e], n = (double)nr;
+                s1[e] = (double)f1[e] + n * c;
+                s2[e] = bwd ? (double)f2[e] : (double)f2[e] + 2.0 * c * (double)f1[e] + n * c * c;
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             if (bwd) {
@@ -209,6 +244,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 s1[e] += __shfl_xor(s1[e], o, 64);
                 s2[e] += __shfl_xor(s2[e], o, 64);
             }
+        }
         }
         __syncthreads();                                   // staging tile no longer read: s_red may alias it
         if (lane < CVN) {

