@@ -108,6 +108,13 @@ class Op:
         elif k == 'wgrad':
             rd = [b(self.x), b(self.dy)] + bn_bufs(self.bn)
             wr = [self.dw, self.dbias]
+        elif k == 'affsum':                    # y = relu?(sum_j bn_j(up_j(x_j))) -- HRNet block tails and fuse layers
+            rd = [b(t) for t, _, _ in self.terms]
+            for _, bn, _ in self.terms:
+                rd += bn_bufs(bn)
+            wr = [b(self.y), self.out_stats]
+        elif k == 'nchw2nhwc':
+            rd, wr = [self.image], [b(self.y)]
         elif k == 'wreduce':                   # sums the slabs of its weight gradients into dw / dbias
             rd, wr = list(self.bufs), list(self.bufs)
         elif k == 'grad_ready':                # marker: every gradient of one bucket is final once this op has run
@@ -322,25 +329,31 @@ class HourglassGraph:
         self._lane = 0                         # lane 0 = the caller's stream; 1..depth = hourglass up-branches
         self.lane_levels = LANE_LEVELS if lane_levels is None else lane_levels
         self.wgrad_batch = WGRAD_BATCH if wgrad_batch is None else wgrad_batch
+        self._setup()
+
+    MASTER_ONLY = ('conv1.weight',)            # convolutions whose kernels read the fp32 master weights (hourglass stem)
+
+    def _setup(self):
+        """Shared tail of the constructors: op lists, working-weight copies, forward and backward construction."""
         self._wg_pending = []
-        self.n_lanes = 1 + depth + WGRAD_LANES
+        self.n_lanes = 1 + self.depth + WGRAD_LANES
         self.fwd, self.bwd = _OpList(self), _OpList(self)
         self.bns = []                          # train-mode BNs in forward order (running-stat update table)
-        self.image = Buf('image', 0, (batch, 3, height, width), 'image')
+        self.image = Buf('image', 0, (self.N, 3, self.H, self.W), 'image')
         self.outputs = []
         self._bn_pending = {}
         self._bn_uses = {}
         for k in self.p.conv_keys():
-            if k == 'conv1.weight':
-                continue                       # stem reads the fp32 master weights
+            if k in self.MASTER_ONLY:
+                continue
             b = self.p[k]
-            if not wlp_is_master:
+            if not self.wlp_is_master:
                 self.wfwd[k] = self._wlp(b)
-            if train:
+            if self.train:
                 K, R, S, C = b.shape
                 self.wbwd[k] = self._wlp(Buf('param', 0, (C, R, S, K)))
         self.build_forward()
-        if train:
+        if self.train:
             self.build_backward()
 
     # ---- small allocators ----
@@ -361,16 +374,17 @@ class HourglassGraph:
                   g[name + '.running_var'], g[name + '.num_batches_tracked'])
 
     # ---- forward primitives ----
-    def conv(self, x, name, bn=None, residual=None, pad=0, sink=None):
+    def conv(self, x, name, bn=None, residual=None, pad=0, sink=None, stride=1):
         wkey = name + '.weight'
         K, R, S, C = self.p[wkey].shape
         n, h, w, c = x.shape
         assert c == C, (name, x.shape, self.p[wkey].shape)
-        y = Act((n, h + 2 * pad - R + 1, w + 2 * pad - S + 1, K), name)
+        y = Act((n, (h + 2 * pad - R) // stride + 1, (w + 2 * pad - S) // stride + 1, K), name)
         wbuf = self.p[wkey] if self.wlp_is_master else self.wfwd[wkey]
-        op = Op('conv', x=x, w=wbuf, wkey=wkey, bias=self.p[name + '.bias'], bkey=name + '.bias', residual=residual,
+        bkey = name + '.bias' if (name + '.bias') in self.p.entries else None      # HRNet convolutions carry no bias
+        op = Op('conv', x=x, w=wbuf, wkey=wkey, bias=self.p[bkey] if bkey else None, bkey=bkey, residual=residual,
                 y=y, out_stats=None, bn=bn, epi='plain', epi_x=None, epi_bn=None, epi_stats=None,
-                dims=(n, h, w, C, K, R, S, 1, pad, y.shape[1], y.shape[2]))
+                dims=(n, h, w, C, K, R, S, stride, pad, y.shape[1], y.shape[2]))
         y.producer = op
         if bn is not None:
             self._use_bn(x, bn)
@@ -639,6 +653,8 @@ class HourglassGraph:
                                    dbias=self.p.grad('conv1.bias'), dims=op.dims, lane=1 + self.depth))
             elif op.kind == 'ew':
                 self._ew_backward(op)
+            elif op.kind == 'affsum':
+                self._affsum_backward(op)
         self._lane = 0
         self._close_bucket(self._cur_bucket if self._cur_bucket is not None else 0)
         assert not self._bn_pending, 'unfinished BN backward: %r' % list(self._bn_pending)
@@ -652,6 +668,9 @@ class HourglassGraph:
             key = 'conv1.weight'
         if key is None and getattr(op, 'bn', None) is not None:
             key = op.bn.name + '.weight'
+        if key is None and op.kind == 'affsum':
+            names = [bn.name for _, bn, _ in op.terms if bn is not None]
+            key = names[0] + '.weight' if names else None
         return None if key is None else self.p.bucket[key]
 
     def _close_bucket(self, b):
@@ -691,14 +710,25 @@ class HourglassGraph:
         if dy is None:
             return
         x = op.x
-        self._wg_pending.append(Op('wgrad', x=x, dy=dy, dw=self.p.grad(op.wkey), dbias=self.p.grad(op.bkey), bn=op.bn,
-                                   dims=op.dims, lane=1 + self.depth))
+        self._wg_pending.append(Op('wgrad', x=x, dy=dy, dw=self.p.grad(op.wkey), dbias=self.p.grad(op.bkey) if op.bkey else None,
+                                   bn=op.bn, dims=op.dims, lane=1 + self.depth))
         if op.residual is not None:
             self._contribute_identity(op.residual, dy)
         if not x.needs_grad:
             return
         n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
         ddims = (n, P, Q, K, C, R, S, 1, R - 1 - pad, h, w)      # dgrad = conv of dy with the flipped IO-swapped weights
+        if stride == 2:
+            # stride-2 convolution (HRNet stem / transition / fuse layers, pose_hrnet.py:223-242,349-372): its data gradient
+            # is the stride-1 convolution of the ZERO-DILATED output gradient (dy written to the even positions of an
+            # input-sized grid) with the same flipped weights
+            assert h == 2 * P and w == 2 * Q, 'stride-2 data gradient needs even input dims, got %dx%d' % (h, w)
+            dil = Act((n, h, w, K), 'dil:' + op.wkey)
+            self.bwd.append(Op('ew', op='dilate2', dims=(n, h, w, K), x=dy, x2=None, dy=None, add=None, y=dil,
+                               out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None))
+            dy, ddims = dil, (n, h, w, K, C, R, S, 1, R - 1 - pad, h, w)
+        else:
+            assert stride == 1
         wb = self.wbwd[op.wkey]
         if op.bn is not None:
             def make(dz, add, bstats, op=op, dy=dy, x=x):
@@ -711,6 +741,43 @@ class HourglassGraph:
             self._emit_dgrad(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=out,
                                 out_stats=None, bn=None, epi='plain', epi_x=None, epi_bn=None, epi_stats=None, dims=ddims,
                                 lane=self._home(x) if add is not None else None))
+
+    def _affsum_backward(self, op):
+        """y = relu(sum_j bn_j(up_j(x_j))): the masked gradient g = dy * (y > 0) reaches every term; an up-sampled term
+        receives its f x f block sums; a normalised term goes through the BatchNorm backward (two sums, then apply)."""
+        dy = op.y.grad
+        if dy is None:
+            return
+
+        def ew(name, dims, **kw):
+            f = dict(x=None, x2=None, dy=None, add=None, y=None, out_stats=None, bstats=None, dgamma=None, dbeta=None, bn=None)
+            f.update(kw)
+            o = Op('ew', op=name, dims=tuple(dims), **f)
+            self.bwd.append(o)
+            return o
+        g = dy
+        if op.relu:
+            g = Act(op.y.shape, 'g:' + op.y.name)
+            ew('relu_mask', op.y.shape, x=op.y, dy=dy, y=g)
+        for t, bn, up in op.terms:
+            if not t.needs_grad:
+                continue
+            gj = g
+            f = up
+            while f > 1:                      # nearest x2^k up-sampling backward = k 2x2 block sums
+                nxt = Act((gj.shape[0], gj.shape[1] // 2, gj.shape[2] // 2, gj.shape[3]), 'gs:' + t.name)
+                ew('sumpool', gj.shape, x=gj, y=nxt)
+                gj, f = nxt, f // 2
+            if bn is None:
+                self._contribute_identity(t, gj)
+                continue
+            if bn.mode != 'train':
+                raise AssertionError('backward through an eval-mode BN term')
+            bstats = self._stats(bn.C, 'bstats:' + bn.name)
+            ew('bnrelu_bwd_r', t.shape, x=t, dy=gj, y=None, bstats=bstats, bn=bn)          # statistics only (y = None)
+            add, out = self._contribute(t)
+            ew('bn_bwd_apply', t.shape, x=t, dy=gj, add=add, y=out, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
+               dbeta=self.p.grad(bn.name + '.bias'), bn=bn)
 
     def _ew_backward(self, op):
         dy = op.y.grad
@@ -735,3 +802,169 @@ class HourglassGraph:
             self._bn_backward_contribution(x, bn, make)
         else:
             raise AssertionError(op.op)
+
+
+# ------------------------------------------------------------------------------------------------
+# HRNet graph
+# ------------------------------------------------------------------------------------------------
+HRNET_EXPANSION = {'BASIC': 1, 'BOTTLENECK': 4}
+
+
+def hrnet_bucket_of(key):
+    """Gradient buckets of an HRNet in backward completion order: stage4 + head, stage3 (+ transition3), stage2
+    (+ transition2), then layer1 / stem / transition1."""
+    p = key.split('.')[0]
+    return {'final_layer': 0, 'stage4': 0, 'transition3': 1, 'stage3': 1, 'transition2': 2, 'stage2': 2}.get(p, 3)
+
+
+class HRNetGraph(HourglassGraph):
+    """Op lists of /root/reference/lib/models/pose_hrnet.py (PoseHighResolutionNet.forward :425-460 and everything it
+    calls: Bottleneck :78-98, BasicBlock :41-57, HighResolutionModule :247-265 with its fuse layers :187-242, the
+    transition layers :333-372) and of its autograd, in the same IR as the hourglass.
+
+    HRNet is post-activation: conv -> BN -> ReLU.  Where a normalised tensor has ONE consumer and that consumer is a
+    convolution (inside the blocks, inside the stride-2 chains, the first stem BN), BN+ReLU are folded into the
+    consumer's operand load exactly like the hourglass' pre-activation BNs; where it ends a block, a fuse sum or a
+    transition (several consumers / a residual add), ONE 'affsum' op materialises y = relu(sum_j bn_j(up_j(x_j))):
+    the block tail relu(bn2(conv2) + skip), the fuse layer relu(sum of identity / 1x1+BN+nearest-up / strided terms)."""
+
+    MASTER_ONLY = ()
+
+    def __init__(self, params, extra, num_joints, batch, height, width, train, wlp_is_master=True, wgrad_batch=None):
+        self.p = params
+        self.extra, self.J = extra, num_joints
+        self.S = 1                                 # one heat-map
+        self.N, self.H, self.W = batch, height, width
+        self.train, self.depth = train, 4
+        self.wlp_is_master = wlp_is_master
+        self.fuse_bneck = self.fuse_head = False
+        self.pair_branches = False
+        self._pair_op = self._pair_ew = None
+        self.stats_size = self.fold_size = self.wlp_size = 0
+        self.wfwd, self.wbwd = {}, {}
+        self._lane = 0
+        self.lane_levels = 0
+        self.wgrad_batch = WGRAD_BATCH if wgrad_batch is None else wgrad_batch
+        self._setup()
+
+    # ---- forward primitives ----
+    def _bnx(self, name, C, relu):
+        bn = self._bn(name, C)
+        bn.relu = relu
+        return bn
+
+    def affsum(self, terms, name, relu=True):
+        """terms: [(act, bn or None, up factor)]; the first term fixes the output shape."""
+        t0, _, f0 = terms[0]
+        n, h, w, c = t0.shape
+        shape = (n, h * f0, w * f0, c)
+        for t, bn, f in terms:
+            assert (t.shape[0], t.shape[1] * f, t.shape[2] * f, t.shape[3]) == shape, (name, t.shape, f, shape)
+            if bn is not None:
+                self._use_bn(t, bn)
+        y = Act(shape, name)
+        op = Op('affsum', terms=list(terms), y=y, relu=relu, out_stats=None, dims=shape, extra_in=[t for t, _, _ in terms])
+        y.producer = op
+        self.fwd.append(op)
+        return y
+
+    def block(self, x, p, kind, stride=1):
+        """pose_hrnet.py:41-57 (BASIC) / :78-98 (BOTTLENECK)."""
+        planes = self.p[p + 'conv1.weight'].shape[0]
+        if kind == 'BASIC':
+            t = self.conv(x, p + 'conv1', pad=1, stride=stride)
+            t = self.conv(t, p + 'conv2', bn=self._bnx(p + 'bn1', planes, True), pad=1)
+            tail = (t, self._bnx(p + 'bn2', planes, False), 1)
+        else:
+            t = self.conv(x, p + 'conv1')
+            t = self.conv(t, p + 'conv2', bn=self._bnx(p + 'bn1', planes, True), pad=1, stride=stride)
+            t = self.conv(t, p + 'conv3', bn=self._bnx(p + 'bn2', planes, True))
+            tail = (t, self._bnx(p + 'bn3', 4 * planes, False), 1)
+        if (p + 'downsample.0.weight') in self.p.entries:
+            d = self.conv(x, p + 'downsample.0', stride=stride)
+            skip = (d, self._bnx(p + 'downsample.1', d.shape[3], False), 1)
+        else:
+            skip = (x, None, 1)
+        return self.affsum([tail, skip], p + 'out')
+
+    def hr_module(self, xs, p, sc, multi_scale_output):
+        """pose_hrnet.py:247-265."""
+        nb = len(xs)
+        ys = []
+        for i in range(nb):
+            y = xs[i]
+            for b in range(sc['NUM_BLOCKS'][i]):
+                y = self.block(y, '%sbranches.%d.%d.' % (p, i, b), sc['BLOCK'])
+            ys.append(y)
+        if nb == 1:
+            return ys
+        outs = []
+        for i in range(nb if multi_scale_output else 1):
+            terms = []
+            for j in range(nb):
+                q = '%sfuse_layers.%d.%d.' % (p, i, j)
+                if j == i:
+                    terms.append((ys[j], None, 1))
+                elif j > i:                      # :199-211: 1x1 conv + BN, nearest up-sampling by 2^(j-i)
+                    t = self.conv(ys[j], q + '0')
+                    terms.append((t, self._bnx(q + '1', t.shape[3], False), 2 ** (j - i)))
+                else:                            # :214-241: (i-j) stride-2 3x3 convs, BN after each, ReLU except after the last
+                    t, bn = ys[j], None
+                    for k in range(i - j):
+                        t = self.conv(t, '%s%d.0' % (q, k), bn=bn, pad=1, stride=2)
+                        bn = self._bnx('%s%d.1' % (q, k), t.shape[3], k != i - j - 1)
+                    terms.append((t, bn, 1))
+            terms.sort(key=lambda tm: tm[2])     # a full-resolution term first: it fixes the output shape
+            outs.append(self.affsum(terms, '%sfuse%d' % (p, i)))
+        return outs
+
+    def transition(self, ys, p, pre, cur):
+        """pose_hrnet.py:333-372 as applied in forward() (:436-457): missing layer = pass-through; every layer is fed the
+        LAST branch of the previous stage."""
+        xs = []
+        for i, c in enumerate(cur):
+            q = '%s%d.' % (p, i)
+            if i < len(pre):
+                if c != pre[i]:
+                    t = self.conv(ys[-1], q + '0', pad=1)
+                    xs.append(self.affsum([(t, self._bnx(q + '1', c, False), 1)], q + 'out'))
+                else:
+                    xs.append(ys[i])
+            else:
+                t, bn = ys[-1], None
+                nlay = i + 1 - len(pre)
+                for j in range(nlay):
+                    t = self.conv(t, '%s%d.0' % (q, j), bn=bn, pad=1, stride=2)
+                    bn = self._bnx('%s%d.1' % (q, j), t.shape[3], True)
+                bn.relu = False                  # the affsum op applies the final ReLU itself
+                xs.append(self.affsum([(t, bn, 1)], q + 'out'))
+        return xs
+
+    def build_forward(self):
+        """pose_hrnet.py:425-460."""
+        x0 = Act((self.N, self.H, self.W, 3), 'image_nhwc')
+        x0.needs_grad = False
+        op = Op('nchw2nhwc', image=self.image, y=x0, dims=(self.N, 3, self.H, self.W), extra_out=[])
+        x0.producer = op
+        self.fwd.append(op)
+        t = self.conv(x0, 'conv1', pad=1, stride=2)
+        t = self.conv(t, 'conv2', bn=self._bnx('bn1', 64, True), pad=1, stride=2)
+        x = self.affsum([(t, self._bnx('bn2', 64, False), 1)], 'stem')
+        for b in range(4):
+            x = self.block(x, 'layer1.%d.' % b, 'BOTTLENECK')
+        chans = [[c * HRNET_EXPANSION[self.extra[s]['BLOCK']] for c in self.extra[s]['NUM_CHANNELS']]
+                 for s in ('STAGE2', 'STAGE3', 'STAGE4')]
+        ys, pre = [x], [256]
+        for si, sname in enumerate(('STAGE2', 'STAGE3', 'STAGE4')):
+            sc = self.extra[sname]
+            xs = self.transition(ys, 'transition%d.' % (si + 1), pre, chans[si])
+            for m in range(sc['NUM_MODULES']):
+                last = sname == 'STAGE4' and m == sc['NUM_MODULES'] - 1
+                xs = self.hr_module(xs, 'stage%d.%d.' % (si + 2, m), sc, not last)
+            ys, pre = xs, chans[si]
+        k = self.extra.get('FINAL_CONV_KERNEL', 1)
+        out = self.conv(ys[0], 'final_layer', pad=1 if k == 3 else 0)
+        out.persistent = True
+        self.outputs.append(out)
+        if self.train:
+            self.fwd.append(Op('bnupd', bns=list(self.bns)))

@@ -188,7 +188,17 @@ def run_ew(A, op):
         st = A.view(op.bstats)[0]
         st[0] += dzr.sum((0, 1, 2))
         st[1] += (dzr * ((x - mean) * invstd).double()).sum((0, 1, 2))
-        _store(A, op.y, dz)
+        if op.y is not None:                      # y None: statistics only (BN terms of an affsum op)
+            _store(A, op.y, dz)
+    elif name == 'relu_mask':                     # g = dy where the forward output y (op.x) is positive
+        y, dy = _act(A, op.x), _act(A, op.dy)
+        _store(A, op.y, torch.where(y > 0, dy, torch.zeros_like(dy)))
+    elif name == 'dilate2':                       # zero-dilation: out[n, 2p, 2q] = x[n, p, q], zero elsewhere
+        x = _act(A, op.x)
+        n, h, w, c = op.dims
+        out = torch.zeros(n, h, w, c)
+        out[:, 0::2, 0::2] = x
+        _store(A, op.y, out)
     elif name == 'bn_bwd_apply':
         x, dz = _act(A, op.x), _act(A, op.dy)
         _, _, mean, invstd = _bn_coef(A, op.bn)
@@ -231,6 +241,34 @@ def run_ew(A, op):
         _store(A, op.y, _act(A, op.x) + _act(A, op.x2))
     else:
         raise AssertionError(name)
+
+
+def run_affsum(A, op):
+    """include/fpd_amd.h fpd_affsum_t: y = relu?(sum_j bn_j(nearest_up_fj(x_j))) -- HRNet block tails
+    (/root/reference/lib/models/pose_hrnet.py:52-57,93-98), fuse layers (:252-265) and transition outputs.  Each
+    normalised term is evaluated as x*scale + shift in fp32, the sum is rounded to the storage precision once."""
+    acc = None
+    for t, bn, f in op.terms:
+        v = _act(A, t)
+        if bn is not None:
+            scale, shift, _, _ = _bn_coef(A, bn)
+            v = torch.addcmul(shift, v, scale)
+            if bn.relu:
+                v = v.clamp_min(0)
+        if f > 1:
+            v = v.repeat_interleave(f, dim=1).repeat_interleave(f, dim=2)
+        acc = v if acc is None else acc + v
+    if op.relu:
+        acc = acc.clamp_min(0)
+    y = _rnd(A, acc)
+    if op.out_stats is not None:
+        _stats_add(A, op.out_stats, y)
+    _store(A, op.y, y)
+
+
+def run_nchw2nhwc(A, op):
+    n, c, h, w = op.dims
+    _store(A, op.y, A.view(op.image).view(n, c, h, w).permute(0, 2, 3, 1))
 
 
 def run_bnupd(A, op, momentum=0.1):
@@ -285,7 +323,8 @@ RUN = {'conv': run_conv, 'wgrad': run_wgrad, 'stem_fwd': run_stem_fwd, 'stem_wgr
        'head': run_head, 'head_fold': lambda A, op: None,
        # the interpreter's wgrad accumulates straight into dw (no slabs): the slab reduction and the bucket marker of
        # the device plan have no effect on the specification
-       'wreduce': lambda A, op: None, 'grad_ready': lambda A, op: None}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
+       'wreduce': lambda A, op: None, 'grad_ready': lambda A, op: None,
+       'affsum': run_affsum, 'nchw2nhwc': run_nchw2nhwc}       # one launch, two independent convolutions       # device-side table preparation: no effect on the specification
 
 
 def run(A, ops):

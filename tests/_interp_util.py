@@ -27,7 +27,7 @@ def make_arenas(g, table, act_size, act_dtype=torch.float32, extra=None):
 def wprep_op(g, table):
     entries = []
     for k in table.conv_keys():
-        if k == 'conv1.weight':
+        if k in getattr(g, 'MASTER_ONLY', ('conv1.weight',)):
             continue
         entries.append({'w': table[k], 'w_fwd': g.wfwd.get(k), 'w_bwd': g.wbwd.get(k)})
     return G.Op('wprep', entries=entries)
