@@ -30,6 +30,7 @@ int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
 int fpd_elementwise_pair_launch(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st);
+int fpd_affsum_launch(const fpd_affsum_t& a, hipStream_t st);
 int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st);
 int fpd_adam_launch(const fpd_adam_t& a, hipStream_t st);
 int fpd_weight_prep_launch(const fpd_wprep_entry_t* table, int n, int64_t max_elems, int dtype, hipStream_t st);
@@ -77,7 +78,7 @@ int fpd_set_backend(int32_t backend) {
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
-    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t); SZ(fpd_head_t);
+    SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t); SZ(fpd_head_t); SZ(fpd_affsum_t); SZ(fpd_layout_t);
 #undef SZ
     return -1;
 }
@@ -215,8 +216,26 @@ int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream) {
     return rc ? rc : check_launch();
 }
 
+int fpd_affsum(const fpd_affsum_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->y, "affsum: null pointer");
+    FPD_REQUIRE(a->nterms >= 1 && a->nterms <= FPD_AFFSUM_MAX, "affsum: %d terms (1..%d supported)", a->nterms, FPD_AFFSUM_MAX);
+    FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "affsum: bad dtype %d", a->dtype);
+    for (int j = 0; j < a->nterms; ++j) {
+        const int up = a->t[j].up;
+        FPD_REQUIRE(a->t[j].x, "affsum: term %d has no input", j);
+        FPD_REQUIRE((up == 1 || up == 2 || up == 4 || up == 8) && a->H % up == 0 && a->W % up == 0,
+                    "affsum: term %d: up-sampling factor %d does not divide %dx%d", j, up, a->H, a->W);
+        const fpd_bn_t& bn = a->t[j].bn;
+        FPD_REQUIRE(bn.mode == FPD_BN_NONE || (bn.gamma && bn.beta), "affsum: term %d: BN without gamma/beta", j);
+        FPD_REQUIRE(bn.mode != FPD_BN_TRAIN || bn.stats, "affsum: term %d: train-mode BN without statistics", j);
+        FPD_REQUIRE(bn.mode != FPD_BN_EVAL || (bn.running_mean && bn.running_var), "affsum: term %d: eval-mode BN without running stats", j);
+    }
+    int rc = fpd_affsum_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
 int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream) {
-    FPD_REQUIRE(a && a->y, "elementwise: null pointer");
+    FPD_REQUIRE(a && (a->y || a->op == FPD_EW_BNRELU_BWD_R), "elementwise: null pointer");
     int rc = fpd_elementwise_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
@@ -302,7 +321,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_head_t head; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_affsum_t affsum; fpd_layout_t layout; fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_head_t head; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -357,6 +376,8 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_LOSS: want = sizeof(fpd_loss_t); break;
         case FPD_OP_ADAM: want = sizeof(fpd_adam_t); break;
         case FPD_OP_MEMSET: case FPD_OP_NOP: want = sizeof(fpd_memset_t); break;
+        case FPD_OP_AFFSUM: want = sizeof(fpd_affsum_t); break;
+        case FPD_OP_NCHW2NHWC: want = sizeof(fpd_layout_t); break;
         case FPD_OP_WPREP: case FPD_OP_BNUPD: case FPD_OP_WREDUCE: want = sizeof(fpd_table_t); break;
         default: return fpd_fail(-2, "plan_add: unknown op %d", op);
     }
@@ -415,6 +436,9 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
             return 0;
         }
         case FPD_OP_NOP: return 0;
+        case FPD_OP_AFFSUM: return fpd_affsum(&o.u.affsum, s);
+        case FPD_OP_NCHW2NHWC:
+            return fpd_nchw_to_nhwc(o.u.layout.src, o.u.layout.dst, o.u.layout.N, o.u.layout.C, o.u.layout.H, o.u.layout.W, o.u.layout.dtype, s);
         case FPD_OP_WPREP:
             return fpd_weight_prep((const fpd_wprep_entry_t*)o.u.table.table, o.u.table.n, o.u.table.max_elems, o.u.table.dtype, s);
         case FPD_OP_BNUPD: return fpd_bn_update_running((const fpd_bnupd_entry_t*)o.u.table.table, o.u.table.n, s);

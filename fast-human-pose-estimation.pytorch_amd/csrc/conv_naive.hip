@@ -25,6 +25,17 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
     const T* ex = reinterpret_cast<const T*>(a.epi_x);
     T* y = reinterpret_cast<T*>(a.y);
     const size_t total = (size_t)M * K;
+    // statistics: when the grid stride is a multiple of K a thread sees ONE output channel in all its iterations, so it keeps
+    // its two sums in registers (fp64) and the block adds them per channel at the end (LDS, then one atomic pair per channel
+    // per block) -- per-element atomics otherwise (tiny / odd K only)
+    const bool want_stats = a.epi == FPD_EPI_BNRELU_BWD || a.out_stats != nullptr;
+    const bool fast = want_stats && ((size_t)gridDim.x * blockDim.x) % (size_t)K == 0 && K <= FPD_MAXC;
+    __shared__ double s_acc[2][FPD_MAXC];
+    if (fast) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) { s_acc[0][k] = 0.0; s_acc[1][k] = 0.0; }
+        __syncthreads();
+    }
+    double t1 = 0.0, t2 = 0.0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / K), k = (int)(idx - (size_t)m * K);
         const int n = m / (P * Q), rem = m - n * (P * Q);
@@ -52,18 +63,38 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
             const float z = fmaf(xv, s_epi[0][k], s_epi[1][k]);
             v = (!a.epi_bn.relu || z > 0.f) ? v : 0.f;
             const float vr = DT<T>::rnd(v);
-            atomicAdd(a.epi_stats + stats_replica() * 2 * K + k, (double)vr);
-            atomicAdd(a.epi_stats + stats_replica() * 2 * K + K + k, (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k])));
+            const double u2 = (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k]));
+            if (fast) { t1 += (double)vr; t2 += u2; }
+            else {
+                atomicAdd(a.epi_stats + stats_replica() * 2 * K + k, (double)vr);
+                atomicAdd(a.epi_stats + stats_replica() * 2 * K + K + k, u2);
+            }
         } else if (a.out_stats) {
             const float vr = DT<T>::rnd(v);
-            atomicAdd(a.out_stats + stats_replica() * 2 * K + k, (double)vr);
-            atomicAdd(a.out_stats + stats_replica() * 2 * K + K + k, (double)(vr * vr));
+            if (fast) { t1 += (double)vr; t2 += (double)vr * (double)vr; }
+            else {
+                atomicAdd(a.out_stats + stats_replica() * 2 * K + k, (double)vr);
+                atomicAdd(a.out_stats + stats_replica() * 2 * K + K + k, (double)(vr * vr));
+            }
         }
         DT<T>::st(y + idx, v);
     }
+    if (fast) {
+        const int k = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % (size_t)K);
+        atomicAdd(&s_acc[0][k], t1);
+        atomicAdd(&s_acc[1][k], t2);
+        __syncthreads();
+        double* dst = (a.epi == FPD_EPI_BNRELU_BWD ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
+        for (int c = threadIdx.x; c < K; c += blockDim.x) {
+            atomicAdd(dst + c, s_acc[0][c]);
+            atomicAdd(dst + K + c, s_acc[1][c]);
+        }
+    }
 }
 
-// one thread per weight element, serial loop over all pixels (deterministic; debugging / odd shapes)
+// one thread per weight element and pixel chunk (blockIdx.y): serial loop over the chunk's pixels, one fp32 atomic per
+// thread at the end (dw / dbias are accumulators the caller zeroes).  Odd shapes: channel counts that are not multiples
+// of 16 -- the 3-channel first convolution of HRNet (pose_hrnet.py:279), J = 17 heads, the scaled-down test networks.
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
     __shared__ float s_scale[FPD_MAXC], s_shift[FPD_MAXC];
@@ -78,7 +109,9 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
     if (idx >= total) return;
     const int c = idx % C, s = (idx / C) % S, r = (idx / (C * S)) % R, k = idx / (C * S * R);
     float acc = 0.f, bsum = 0.f;
-    for (int m = 0; m < M; ++m) {
+    const int per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int m_begin = (int)blockIdx.y * per, m_end = min(M, m_begin + per);
+    for (int m = m_begin; m < m_end; ++m) {
         const float g = DT<T>::ld(dy + (size_t)m * K + k);
         bsum += g;
         const int n = m / (P * Q), rem = m - n * (P * Q);
@@ -89,8 +122,8 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
         if (a.bn.mode != FPD_BN_NONE) xv = DT<T>::rnd(bn_act(xv, s_scale[c], s_shift[c], a.bn.relu));
         acc = fmaf(g, xv, acc);
     }
-    a.dw[idx] += acc;
-    if (a.dbias && c == 0 && r == 0 && s == 0) a.dbias[k] += bsum;
+    atomicAdd(a.dw + idx, acc);
+    if (a.dbias && c == 0 && r == 0 && s == 0) atomicAdd(a.dbias + k, bsum);
 }
 
 }  // namespace
@@ -98,7 +131,8 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st) {
     if (a.C > FPD_MAXC || a.K > FPD_MAXC) return fpd_fail(-3, "conv: channel count above %d", FPD_MAXC);
     const size_t total = (size_t)a.N * a.P * a.Q * a.K;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+    const bool stats = a.out_stats != nullptr || a.epi == FPD_EPI_BNRELU_BWD;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, stats ? 2048 : 65536);    // statistics: few, long-lived blocks
     if (a.dtype == FPD_BF16)
         hipLaunchKernelGGL((conv_naive_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
     else
@@ -109,9 +143,11 @@ int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st) {
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st) {
     if (a.C > FPD_MAXC) return fpd_fail(-3, "wgrad: channel count above %d", FPD_MAXC);
     const int total = a.K * a.R * a.S * a.C;
+    const int M = a.N * a.P * a.Q;
+    const int chunks = std::max(1, std::min(1024, M / 512));          // >= 512 pixels per thread
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
     return 0;
 }

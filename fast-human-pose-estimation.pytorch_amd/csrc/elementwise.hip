@@ -98,6 +98,20 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
                     acc1[j] += r;
                     acc2[j] += r * (double)((v[j] - s_t2[cv + j]) * s_t3[cv + j]);
                 }
+                if (y != nullptr) stv<T>(y + (size_t)pix * C + cv, o);     // y NULL: the two sums only
+            } else if (OP == FPD_EW_RELU_MASK) {
+                float v[VEC], g[VEC];
+                ldv<T>(x + (size_t)pix * C + cv, v);
+                ldv<T>(dy + (size_t)pix * C + cv, g);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = v[j] > 0.f ? g[j] : 0.f;
+                stv<T>(y + (size_t)pix * C + cv, o);
+            } else if (OP == FPD_EW_DILATE2) {
+                const int n = pix / (H * W), rem = pix - n * (H * W);
+                const int oy = rem / W, ox = rem - oy * W;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+                if (((oy | ox) & 1) == 0) ldv<T>(x + ((size_t)(n * (H / 2) + oy / 2) * (W / 2) + ox / 2) * C + cv, o);
                 stv<T>(y + (size_t)pix * C + cv, o);
             } else if (OP == FPD_EW_BN_BWD_APPLY) {
                 float v[VEC], g[VEC], ad[VEC];
@@ -228,6 +242,57 @@ int launch_ew_pair(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st) {
     return 0;
 }
 
+// y = relu?(sum_j bn_j(up_j(x_j))), see fpd_affsum_t.  Same thread layout as ew_body: a thread owns one channel vector and
+// walks output pixels grid-stride; per-term scale/shift tables in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void affsum_kernel(const fpd_affsum_t a) {
+    constexpr int VEC = DT<T>::VEC;
+    __shared__ float s_sc[FPD_AFFSUM_MAX][FPD_MAXC], s_sh[FPD_AFFSUM_MAX][FPD_MAXC];
+    const int tid = threadIdx.x;
+    const int C = a.C, H = a.H, W = a.W;
+    for (int j = 0; j < a.nterms; ++j) {
+        if (a.t[j].bn.mode == FPD_BN_NONE) continue;
+        const int up = a.t[j].up;
+        const double cnt = (double)a.N * (H / up) * (W / up);
+        for (int c = tid; c < C; c += 256) {
+            float sc, sh, mu, is;
+            bn_coef(a.t[j].bn, c, C, cnt, sc, sh, mu, is);
+            s_sc[j][c] = sc;
+            s_sh[j][c] = sh;
+        }
+    }
+    __syncthreads();
+    const int VP = C / VEC, PB = 256 / VP;
+    const int cv = (tid % VP) * VEC, pl = tid / VP;
+    if (pl >= PB) return;
+    const int npix = a.N * H * W;
+    T* y = reinterpret_cast<T*>(a.y);
+    for (int pix = blockIdx.x * PB + pl; pix < npix; pix += gridDim.x * PB) {
+        const int n = pix / (H * W), rem = pix - n * (H * W);
+        const int oy = rem / W, ox = rem - oy * W;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int j = 0; j < a.nterms; ++j) {
+            const int up = a.t[j].up;
+            const T* x = reinterpret_cast<const T*>(a.t[j].x);
+            float v[VEC];
+            ldv<T>(x + ((size_t)(n * (H / up) + oy / up) * (W / up) + ox / up) * C + cv, v);
+            if (a.t[j].bn.mode != FPD_BN_NONE) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = bn_act(v[e], s_sc[j][cv + e], s_sh[j][cv + e], a.t[j].bn.relu);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        stv<T>(y + (size_t)pix * C + cv, acc);
+    }
+}
+
 template <typename T>
 int dispatch_ew(const fpd_ew_t& a, hipStream_t st) {
     switch (a.op) {
@@ -239,6 +304,8 @@ int dispatch_ew(const fpd_ew_t& a, hipStream_t st) {
         case FPD_EW_UPADD_FWD: return launch_ew<T, FPD_EW_UPADD_FWD>(a, st);
         case FPD_EW_SUMPOOL: return launch_ew<T, FPD_EW_SUMPOOL>(a, st);
         case FPD_EW_ADD: return launch_ew<T, FPD_EW_ADD>(a, st);
+        case FPD_EW_RELU_MASK: return launch_ew<T, FPD_EW_RELU_MASK>(a, st);
+        case FPD_EW_DILATE2: return launch_ew<T, FPD_EW_DILATE2>(a, st);
     }
     return fpd_fail(-2, "elementwise: unknown op %d", a.op);
 }
@@ -267,7 +334,18 @@ int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st) {
     if (a.C % vec != 0 || a.C > FPD_MAXC || a.C / vec > 128)
         return fpd_fail(-3, "elementwise: C=%d must be a multiple of %d and <= %d", a.C, vec, FPD_MAXC);
     const bool pooled = (a.op == FPD_EW_MAXPOOL_FWD || a.op == FPD_EW_MAXPOOL_BWD || a.op == FPD_EW_SUMPOOL ||
-                         a.op == FPD_EW_UPADD_FWD);
+                         a.op == FPD_EW_UPADD_FWD || a.op == FPD_EW_DILATE2);
     if (pooled && ((a.H & 1) || (a.W & 1))) return fpd_fail(-3, "elementwise: 2x2 ops need even H,W (got %dx%d)", a.H, a.W);
     return a.dtype == FPD_BF16 ? dispatch_ew<bf16_t>(a, st) : dispatch_ew<float>(a, st);
+}
+
+int fpd_affsum_launch(const fpd_affsum_t& a, hipStream_t st) {
+    const int vec = (a.dtype == FPD_BF16) ? 8 : 4;
+    if (a.C % vec != 0 || a.C > FPD_MAXC || a.C / vec > 128)
+        return fpd_fail(-3, "affsum: C=%d must be a multiple of %d and <= %d", a.C, vec, FPD_MAXC);
+    const int PB = 256 / (a.C / vec);
+    const int grid = std::max(1, std::min(cdiv(a.N * a.H * a.W, PB), 2048));
+    if (a.dtype == FPD_BF16) hipLaunchKernelGGL((affsum_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((affsum_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
 }

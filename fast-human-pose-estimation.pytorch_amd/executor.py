@@ -15,7 +15,7 @@ from .schedule import PhaseSchedule
 
 _EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd_apply': R.EW_BN_BWD_APPLY,
        'maxpool_fwd': R.EW_MAXPOOL_FWD, 'maxpool_bwd': R.EW_MAXPOOL_BWD, 'upadd_fwd': R.EW_UPADD_FWD,
-       'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD}
+       'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD, 'relu_mask': R.EW_RELU_MASK, 'dilate2': R.EW_DILATE2}
 _ARENA_DTYPE = {'param': torch.float32, 'grad': torch.float32, 'rstat': torch.float32, 'nbt': torch.int64,
                 'stats': torch.float64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
                 'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32, 'fold': torch.float32}
@@ -248,6 +248,20 @@ class Lowering:
             return R.OP_HEAD_FOLD, self.head(op.target)[1]
         if op.kind == 'bneck_fold':
             return R.OP_BNECK_FOLD, self.bneck(op.target)[1]
+        if op.kind == 'affsum':
+            s = R.AffsumT()
+            (s.N, s.H, s.W, s.C) = op.dims
+            s.dtype, s.relu, s.nterms = self.dtype, 1 if op.relu else 0, len(op.terms)
+            assert len(op.terms) <= R.AFFSUM_MAX and op.out_stats is None
+            for j, (t, bn, up) in enumerate(op.terms):
+                s.t[j].x, s.t[j].bn, s.t[j].up = self.A.ptr(_abuf(t)), self.bn(bn), up
+            s.y = self.A.ptr(_abuf(op.y))
+            return R.OP_AFFSUM, s
+        if op.kind == 'nchw2nhwc':
+            s = R.LayoutT()
+            (s.N, s.C, s.H, s.W) = op.dims
+            s.src, s.dst, s.dtype = self.A.ptr(op.image), self.A.ptr(_abuf(op.y)), self.dtype
+            return R.OP_NCHW2NHWC, s
         if op.kind == 'wreduce':
             return self.wreduce(op)
         if op.kind == 'grad_ready':
@@ -279,12 +293,17 @@ class GraphInstance:
         self._wlp_owner = share_weights_with       # another instance of the same model whose working weights we read
         self.dtype = state.dtype
         env = os.environ.get
-        self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
-                                  num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
-                                  fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
-                                  pair_branches=env('FPD_PAIR', '1') != '0', fuse_head=env('FPD_FUSE_HEAD', '1') != '0',
-                                  lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
+        if cfg.get('arch') == 'hrnet':
+            self.g = G.HRNetGraph(state.table, cfg['extra'], cfg['J'], batch, height, width, train,
+                                  wlp_is_master=(self.dtype == R.F32),
                                   wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
+        else:
+            self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
+                                      num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
+                                      fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
+                                      pair_branches=env('FPD_PAIR', '1') != '0', fuse_head=env('FPD_FUSE_HEAD', '1') != '0',
+                                      lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
+                                      wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
         self.low = Lowering(self.A, self.dtype)
         self.plan = R.Plan()
@@ -335,7 +354,7 @@ class GraphInstance:
         p.add(*self.low.memset('stats'))
         entries = []
         for k in self.state.table.conv_keys():
-            if k == 'conv1.weight':
+            if k in g.MASTER_ONLY:
                 continue
             wf, wb = g.wfwd.get(k), g.wbwd.get(k)
             if wf is not None or wb is not None:

@@ -22,9 +22,9 @@ import math
 import torch
 import torch.nn as nn
 
-from ... import executor as E
 from ... import graph as G
 from ... import runtime as R
+from ._flat import BatchNorm2d, Conv2d, FlatArenaNet, MaxPool2d, ReLU, Upsample, _no_eager  # noqa: F401
 
 BN_MOMENTUM = 0.1
 
@@ -73,37 +73,6 @@ def hourglass_keys(num_feats, num_stacks, num_joints, num_blocks=1, depth=4):
     return keys
 
 
-def _no_eager(self, *a, **kw):
-    raise R.FpdError('%s is executed inside the fused HIP plan of its HourglassNet (model(x) on a CUDA tensor); the '
-                     'leaf modules hold parameters/metadata only -- there is no eager torch path' % type(self).__name__)
-
-
-class Conv2d(nn.Conv2d):
-    """nn.Conv2d metadata + parameters (views of the model's flat arena); storage-less construction."""
-
-    def __init__(self, cin, cout, k, stride=1, padding=0):
-        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=True, device='meta')
-    forward = _no_eager
-
-
-class BatchNorm2d(nn.BatchNorm2d):
-    def __init__(self, c):
-        super().__init__(c, momentum=BN_MOMENTUM, device='meta')
-    forward = _no_eager
-
-
-class ReLU(nn.ReLU):
-    forward = _no_eager
-
-
-class MaxPool2d(nn.MaxPool2d):
-    forward = _no_eager
-
-
-class Upsample(nn.Upsample):
-    forward = _no_eager
-
-
 class Bottleneck(nn.Module):
     """hourglass.py:11-52 (pre-activation, expansion 2): container of bn1, conv1, bn2, conv2, bn3, conv3, relu, downsample."""
     expansion = 2
@@ -138,39 +107,7 @@ class Hourglass(nn.Module):
     forward = _no_eager
 
 
-class _HourglassFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, model, inst, x, *params):
-        inst.image().copy_(x)
-        inst.run('prep')
-        inst.run('fwd')
-        ctx.model, ctx.inst = model, inst
-        outs = []
-        l, st = R.lib(), R.current_stream()
-        for i, o in enumerate(inst.g.outputs):
-            n, h, w, c = o.shape
-            t = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-            R.check(l.fpd_nhwc_to_nchw(inst.A.ptr(o.buf), t.data_ptr(), n, c, h, w, inst.dtype, st), 'nhwc_to_nchw')
-            outs.append(t)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *gouts):
-        inst, model = ctx.inst, ctx.model
-        l, st = R.lib(), R.current_stream()
-        for i, (o, g) in enumerate(zip(inst.g.out_grads, gouts)):
-            n, h, w, c = o.shape
-            if g is None:
-                inst.A.view(o.buf).zero_()
-                continue
-            g = g.contiguous().float()
-            R.check(l.fpd_nchw_to_nhwc(g.data_ptr(), inst.A.ptr(o.buf), n, c, h, w, inst.dtype, st), 'nchw_to_nhwc')
-        inst.run('bwd')
-        model._attach_grads()
-        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
-
-
-class HourglassNet(nn.Module):
+class HourglassNet(FlatArenaNet):
     """Stacked hourglass (Newell et al.) student/teacher of the FPD path, HIP-backed."""
 
     def __init__(self, cfg, **kwargs):
@@ -179,30 +116,12 @@ class HourglassNet(nn.Module):
         self.cfg_hg = {'F': int(extra.NUM_FEATURES), 'S': int(extra.NUM_STACKS), 'J': int(cfg.MODEL.NUM_JOINTS),
                        'num_blocks': int(extra.NUM_BLOCKS)}
         self.num_stacks = self.cfg_hg['S']
-        try:                                  # optional MODEL.DTYPE: 'fp32' (parity build) | 'bf16' (throughput build)
-            cfg_dt = cfg.MODEL['DTYPE'] if 'DTYPE' in cfg.MODEL else 'fp32'
-        except TypeError:
-            cfg_dt = getattr(cfg.MODEL, 'DTYPE', 'fp32')
-        dt = str(kwargs.get('dtype', cfg_dt))
-        self.fpd_dtype = R.BF16 if dt in ('bf16', 'bfloat16') else R.F32
+        self.fpd_dtype = self._dtype_from(cfg, kwargs)
         keys = hourglass_keys(self.cfg_hg['F'], self.cfg_hg['S'], self.cfg_hg['J'], self.cfg_hg['num_blocks'])
-        self.table = G.ParamTable(keys, bucket_of=G.hourglass_bucket_of(self.cfg_hg['S']))
-        self._flat = {n: torch.zeros(max(self.table.sizes[n], 4), dtype=torch.int64 if n == 'nbt' else torch.float32)
-                      for n in ('param', 'rstat', 'nbt')}
-        self._flat_grad = None
-        self._state = None
-        self._instances = {}
+        self._init_flat(G.ParamTable(keys, bucket_of=G.hourglass_bucket_of(self.cfg_hg['S'])))
         self._build_tree()
+        self._bind_tree()
         self.reset_parameters()
-
-    # ---- module tree with the reference's key names, tensors = views of the flat arenas ----
-    def _view(self, key, grad=False):
-        b = self.table[key]
-        flat = self._flat_grad if grad else self._flat[b.arena]
-        v = flat[b.off:b.off + b.numel].view(b.shape)
-        if len(b.shape) == 4:
-            v = v.permute(0, 3, 1, 2)          # K,R,S,C storage presented as the reference's OIHW tensor
-        return v
 
     def _build_tree(self):
         """The reference's module tree (hourglass.py:100-168) in its registration order, then every parameter / buffer
@@ -224,40 +143,6 @@ class HourglassNet(nn.Module):
         self.score = nn.ModuleList([Conv2d(ch, J, 1) for _ in range(S)])
         self.fc_ = nn.ModuleList([Conv2d(ch, ch, 1) for _ in range(S - 1)])
         self.score_ = nn.ModuleList([Conv2d(J, ch, 1) for _ in range(S - 1)])
-        for key, _ in self.table.keys:
-            node, leaf = self._owner(key)
-            if self.table[key].arena == 'param':
-                node._parameters[leaf] = nn.Parameter(self._view(key))
-            else:
-                node._buffers[leaf] = self._view(key)
-        meta = [k for k, v in list(self.named_parameters()) + list(self.named_buffers()) if v.is_meta]
-        assert not meta, 'module tree and key table disagree: %r' % meta[:4]
-
-    def _owner(self, key):
-        parts = key.split('.')
-        node = self
-        for p in parts[:-1]:
-            node = node._modules[p]
-        return node, parts[-1]
-
-    def _relink(self):
-        for key, _ in self.table.keys:
-            node, leaf = self._owner(key)
-            if self.table[key].arena == 'param':
-                node._parameters[leaf].data = self._view(key)
-            else:
-                node._buffers[leaf] = self._view(key)
-
-    def _apply(self, fn, recurse=True):
-        # move / cast the flat arenas as a whole, then re-point every parameter and buffer at them
-        for n in self._flat:
-            t = fn(self._flat[n])
-            self._flat[n] = t if n == 'nbt' else t.float()
-        self._flat_grad = None
-        self._state = None
-        self._instances = {}
-        self._relink()
-        return self
 
     def reset_parameters(self):
         """torch defaults, as the reference relies on (no custom init, hourglass.py:195-197): conv weight and
@@ -282,28 +167,6 @@ class HourglassNet(nn.Module):
                         ws = self.table.logical[base + '.weight']
                         bound = 1.0 / math.sqrt(ws[1] * ws[2] * ws[3])
                         v.uniform_(-bound, bound)
-
-    # ---- device state / plans ----
-    def device_state(self):
-        if self._state is None:
-            dev = self._flat['param'].device
-            if dev.type != 'cuda':
-                raise R.FpdError('HourglassNet must be on a CUDA (ROCm) device: call .cuda() first; no CPU fallback')
-            R.lib()
-            st = E.ModelState.__new__(E.ModelState)
-            st.table, st.device, st.dtype = self.table, dev, self.fpd_dtype
-            st.A = E.Arenas(dev, self.fpd_dtype)
-            for n in ('param', 'rstat', 'nbt'):
-                st.A.t[n] = self._flat[n]
-            self._flat_grad = torch.zeros_like(self._flat['param'])
-            st.A.t['grad'] = self._flat_grad
-            self._state = st
-        return self._state
-
-    def _attach_grads(self):
-        for key in self.table.trainable_keys():
-            node, leaf = self._owner(key)
-            node._parameters[leaf].grad = self._view(key, grad=True)
 
     # ---- shape-only walk in the reference's execution order (hourglass.py:32-52,80-92,170-192) ----
     def shape_forward(self, input_shape):
@@ -377,26 +240,6 @@ class HourglassNet(nn.Module):
             assert c == 3, 'expected an RGB image batch [N,3,H,W]'
             self._instances[key] = E.GraphInstance(st, self.cfg_hg, n, h, w, train=train).finalize()
         return self._instances[key]
-
-    def forward(self, x):
-        if not x.is_cuda:
-            raise R.FpdError('fpd_amd HourglassNet.forward needs a CUDA (ROCm) tensor; there is no CPU path')
-        x = x.float().contiguous()
-        inst = self.instance(x.shape, self.training)
-        if self.training and torch.is_grad_enabled():
-            params = [p for p in self.parameters()]
-            return list(_HourglassFn.apply(self, inst, x, *params))
-        inst.image().copy_(x)
-        inst.run('prep')
-        inst.run('fwd')
-        outs = []
-        l, st = R.lib(), R.current_stream()
-        for o in inst.g.outputs:
-            n, h, w, c = o.shape
-            t = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-            R.check(l.fpd_nhwc_to_nchw(inst.A.ptr(o.buf), t.data_ptr(), n, c, h, w, inst.dtype, st), 'nhwc_to_nchw')
-            outs.append(t)
-        return outs
 
 
 def get_pose_net(cfg, is_train, **kwargs):

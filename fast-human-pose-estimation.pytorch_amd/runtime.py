@@ -14,10 +14,11 @@ BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
 EPI_PLAIN, EPI_BNRELU_BWD = 0, 1
 BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
 (EW_BNRELU_FWD, EW_BNRELU_BWD_R, EW_BN_BWD_APPLY, EW_MAXPOOL_FWD, EW_MAXPOOL_BWD, EW_UPADD_FWD, EW_SUMPOOL,
- EW_ADD) = range(8)
+ EW_ADD, EW_RELU_MASK, EW_DILATE2) = range(10)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
  OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK, OP_HEAD, OP_HEAD_FOLD,
- OP_NOP) = range(20)
+ OP_NOP, OP_AFFSUM, OP_NCHW2NHWC) = range(22)
+AFFSUM_MAX = 4
 MAX_STACKS = 8
 MAXC = 512
 
@@ -79,6 +80,19 @@ class HeadT(C.Structure):
                 ('folded', _vp)]
 
 
+class AffTermT(C.Structure):
+    _fields_ = [('x', _vp), ('bn', BnT), ('up', _i32), ('_pad', _i32)]
+
+
+class AffsumT(C.Structure):
+    _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('C', _i32), ('dtype', _i32), ('relu', _i32), ('nterms', _i32),
+                ('_pad', _i32), ('t', AffTermT * 4), ('y', _vp)]
+
+
+class LayoutT(C.Structure):
+    _fields_ = [('src', _vp), ('dst', _vp), ('N', _i32), ('C', _i32), ('H', _i32), ('W', _i32), ('dtype', _i32), ('_pad', _i32)]
+
+
 class PckT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('dtype', _i32), ('log_slots', _i32), ('thr', C.c_float),
                 ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp), ('losses', _vp)]
@@ -121,7 +135,7 @@ class TableT(C.Structure):
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
-            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT}
+            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT, 'fpd_affsum_t': AffsumT, 'fpd_layout_t': LayoutT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -138,6 +152,7 @@ SYMBOLS = {
     'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),
     'fpd_elementwise_pair': (C.c_int, [C.POINTER(EwPairT), _vp]),
     'fpd_pck': (C.c_int, [C.POINTER(PckT), _vp]),
+    'fpd_affsum': (C.c_int, [C.POINTER(AffsumT), _vp]),
     'fpd_head_forward': (C.c_int, [C.POINTER(HeadT), _vp]),
     'fpd_head_fold': (C.c_int, [C.POINTER(HeadT), _vp]),
     'fpd_loss': (C.c_int, [C.POINTER(LossT), _vp]),

@@ -175,10 +175,15 @@ typedef struct {
  *  UPADD_FWD    y = x + nearest_up2(x2); out_stats += stats(y)         (hourglass.py:90-91)
  *  SUMPOOL      y = add + sum2x2(x)                                    (Upsample backward)
  *  ADD          y = x + x2
+ *  RELU_MASK    y = dy * (x > 0)   (x = the forward OUTPUT of a ReLU; pose_hrnet.py:55,96,261 autograd)
+ *  DILATE2      y[n,2p,2q,:] = x[n,p,q,:], zero elsewhere; N,H,W = shape of y (even H,W).  The data gradient of a
+ *               stride-2 convolution (pose_hrnet.py:223-242,349-372) is the stride-1 convolution of this tensor.
+ * BNRELU_BWD_R with y == NULL accumulates the two sums only.
  */
 enum {
     FPD_EW_BNRELU_FWD = 0, FPD_EW_BNRELU_BWD_R = 1, FPD_EW_BN_BWD_APPLY = 2, FPD_EW_MAXPOOL_FWD = 3,
-    FPD_EW_MAXPOOL_BWD = 4, FPD_EW_UPADD_FWD = 5, FPD_EW_SUMPOOL = 6, FPD_EW_ADD = 7
+    FPD_EW_MAXPOOL_BWD = 4, FPD_EW_UPADD_FWD = 5, FPD_EW_SUMPOOL = 6, FPD_EW_ADD = 7, FPD_EW_RELU_MASK = 8,
+    FPD_EW_DILATE2 = 9
 };
 typedef struct {
     int32_t op, dtype;
@@ -194,6 +199,24 @@ typedef struct {
     float* dbeta;          /* BN_BWD_APPLY: optional [C] <- sum dz      (grad of BN bias) */
     fpd_bn_t bn;
 } fpd_ew_t;
+
+/* y = relu?( sum_j a_j(up_j(x_j)) ): the tail of an HRNet block (pose_hrnet.py:52-57,93-98: relu(bn(conv) + skip)), a fuse
+ * layer (:252-265: relu(sum of identity / 1x1-conv+BN+nearest-up / strided-conv+BN terms)) or a transition output (:349-372)
+ * in ONE pass.  Term j is x_j[n, h/up_j, w/up_j, :] (nearest up-sampling by up_j in {1,2,4,8}), normalised by bn_j (mode
+ * NONE = identity; TRAIN statistics cover the N*(H/up)*(W/up) pixels of x_j; bn_j.relu applies to the term).  The sum is
+ * rounded to the storage type once. */
+#define FPD_AFFSUM_MAX 4
+typedef struct { const void* x; fpd_bn_t bn; int32_t up; int32_t _pad; } fpd_affterm_t;
+typedef struct {
+    int32_t N, H, W, C;    /* output shape [N,H,W,C] */
+    int32_t dtype, relu, nterms, _pad;
+    fpd_affterm_t t[FPD_AFFSUM_MAX];
+    void* y;
+} fpd_affsum_t;
+int fpd_affsum(const fpd_affsum_t* a, fpd_stream_t stream);
+
+/* [N,C,H,W] fp32 image -> [N,H,W,C] activation as a plan op (HRNet stem: its first convolution is a generic NHWC conv) */
+typedef struct { const float* src; void* dst; int32_t N, C, H, W, dtype, _pad; } fpd_layout_t;
 
 /* JointsMSELoss pose + KD over all stacks, forward and backward in one pass
  * (lib/core/loss.py:21-39 called 2*S times at lib/core/function.py:128-134):
@@ -307,7 +330,7 @@ enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
     FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16, FPD_OP_HEAD = 17,
-    FPD_OP_HEAD_FOLD = 18, FPD_OP_NOP = 19
+    FPD_OP_HEAD_FOLD = 18, FPD_OP_NOP = 19, FPD_OP_AFFSUM = 20, FPD_OP_NCHW2NHWC = 21
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

@@ -154,13 +154,47 @@ def test_data_parallel_gradient_is_mean_of_shard_gradients():
     np.testing.assert_allclose(got, ref.numpy(), rtol=1e-4, atol=2e-6 * float(ref.abs().max()))
 
 
-def test_hrnet_factory_fails_loudly():
-    """MODEL.NAME pose_hrnet resolves (like the reference's eval('models.' + NAME + '.get_pose_net')) but the path is not
-    built: a clear error, never a silent torch fallback."""
+def _hrnet_cfg(widths, blocks, modules, joints, init=False, pretrained=''):
+    from fpd_amd.lib.config import CfgNode, _wrap
+    from tests._cases_hrnet import extra_cfg
+    extra = dict(extra_cfg(dict(widths=widths, blocks=blocks, modules=modules)), PRETRAINED_LAYERS=['*'])
+    return _wrap({'MODEL': {'NAME': 'pose_hrnet', 'NUM_JOINTS': joints, 'INIT_WEIGHTS': init, 'PRETRAINED': pretrained, 'EXTRA': extra}})
+
+
+def test_hrnet_module_api_keys_init_and_checkpoint_interop():
+    """models.pose_hrnet.get_pose_net (resolved like the reference's eval('models.' + NAME + '.get_pose_net')): state_dict
+    keys / shapes / order of W32 equal the reference's (oracle key list, asserted equal to the reference module's by
+    tests/golden/make_golden_hrnet.py), typed leaves carry the reference's conv geometry, init_weights follows
+    pose_hrnet.py:462-492, strict checkpoint load works, and a CPU tensor is an error (no eager fallback)."""
+    import torch.nn as nn
     from fpd_amd.lib import models
     from fpd_amd.runtime import FpdError
-    with pytest.raises(FpdError, match='HRNet'):
-        eval('models.pose_hrnet.get_pose_net')(None, is_train=True)
+    from oracle import hrnet_ref
+    from tests._cases_hrnet import extra_cfg
+    cfg = _hrnet_cfg([32, 64, 128, 256], 4, (1, 4, 3), 17)
+    m = eval('models.' + cfg.MODEL.NAME + '.get_pose_net')(cfg, is_train=True)
+    keys = hrnet_ref.hrnet_keys(extra_cfg(dict(widths=[32, 64, 128, 256], blocks=4, modules=(1, 4, 3))), 17)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == keys
+    assert sum(p.numel() for p in m.parameters()) == 28536113                       # README / SURVEY section 8(a)
+    mods = dict(m.named_modules())
+    c1, f = mods['conv1'], mods['stage3.0.fuse_layers.2.0.1.0']
+    assert isinstance(c1, nn.Conv2d) and c1.stride == (2, 2) and c1.padding == (1, 1) and c1.bias is None
+    assert f.stride == (2, 2) and f.kernel_size == (3, 3) and isinstance(mods['stage3.0.fuse_layers.2.0.1.1'], nn.BatchNorm2d)
+    assert mods['final_layer'].bias is not None and mods['final_layer'].kernel_size == (1, 1)
+    assert mods['stage2.0.fuse_layers.0.1.0'].kernel_size == (1, 1) and mods['transition1.1.0.0'].stride == (2, 2)
+    small = _hrnet_cfg([8, 16, 32, 64], 1, (1, 2, 1), 5, init=True)
+    ms = models.pose_hrnet.get_pose_net(small, is_train=True)                       # INIT_WEIGHTS: N(0, 1e-3) convs, BN (1, 0)
+    w = ms.state_dict()['stage2.0.branches.0.0.conv1.weight']
+    assert 5e-4 < float(w.std()) < 2e-3 and float(ms.state_dict()['bn1.weight'].min()) == 1.0
+    assert float(ms.state_dict()['final_layer.bias'].abs().max()) == 0.0
+    sd = fpd_ref.synth_state_dict([(k, tuple(v.shape)) for k, v in ms.state_dict().items()], 3)
+    ms.load_state_dict(sd, strict=True)
+    b = ms.table['stage4.0.branches.3.0.conv2.weight']
+    assert torch.equal(ms._flat['param'][b.off:b.off + b.numel].view(b.shape), sd['stage4.0.branches.3.0.conv2.weight'].permute(0, 2, 3, 1))
+    with pytest.raises(FpdError):
+        ms(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(ValueError):
+        models.pose_hrnet.get_pose_net(_hrnet_cfg([8, 16, 32, 64], 1, (1, 1, 1), 5, init=True, pretrained='/nonexistent.pth'), is_train=True)
 
 
 def test_fused_adam_state_dict_interoperates_with_torch_adam_and_resumes():
