@@ -67,10 +67,13 @@ def cpu_baseline():
     of the benchmark pair with the teacher under no_grad (the faster variant: the stronger baseline)."""
     ncpu = os.cpu_count() or 1
     cfg1, pair = ((64, 2), (64, 2)), ((128, 4), (256, 8))
+    t_begin = time.time()
     sweep = {}
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64, ncpu)}):
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):          # beyond 64 threads these small convolutions only lose
         torch.set_num_threads(nt)
         sweep[nt] = round(2 / _cpu_time(cfg1, 2, 1, True), 3)
+        if time.time() - t_begin > 20:
+            break
     best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
     variants = []
@@ -84,7 +87,8 @@ def cpu_baseline():
     run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, False)
     big_b = 4
     v = run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 2, True)
-    run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 1, False)
+    if time.time() - t_begin < 60:
+        run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 1, False)
     return {'value': round(v, 3), 'unit': 'images/s', 'cores': best, 'kind': 'port',
             'sample': 'same FPD pair (hg4x128 <- hg8x256, 256x256) at batch %d, 2 timed steps after 1 warm-up, torch CPU fp32 '
                       'oracle, teacher under no_grad, %d threads (best of the sweep on %d host CPUs)' % (big_b, best, ncpu),
@@ -337,9 +341,11 @@ def main():
     dom = dominant_kernel(step, R) if (rank == 0 and args.dtype == 'bf16' and not hr) else None
     if dom is not None:
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_bneck64.json')       # HBM bytes/launch from separate --pmc passes
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        for name in ('r02_pmc_bneck64.json', 'r01_pmc_bneck64.json'):      # HBM bytes/launch from separate --pmc passes
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                break
         k_ach = dom['flops'] / (dom['us'] * 1e-6) / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(k_ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(k_ach / peak, 4), 'traffic': traffic, 'kernel': dom['name'],
