@@ -232,15 +232,6 @@ class HourglassNet(FlatArenaNet):
                 conv(self.score_[i], sc)
         return outs
 
-    def instance(self, shape, train):
-        key = (tuple(shape), bool(train))
-        if key not in self._instances:
-            st = self.device_state()
-            n, c, h, w = shape
-            assert c == 3, 'expected an RGB image batch [N,3,H,W]'
-            self._instances[key] = E.GraphInstance(st, self.cfg_hg, n, h, w, train=train).finalize()
-        return self._instances[key]
-
 
 def get_pose_net(cfg, is_train, **kwargs):
     """Same factory signature as the reference (is_train is ignored there too, hourglass.py:195-197)."""

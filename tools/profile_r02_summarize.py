@@ -34,7 +34,9 @@ for f in glob.glob('%s/stats/**/*kernel_stats.csv' % out, recursive=True):
     shutil.copy(f, os.path.join(out, 'r02_kernel_stats.csv'))
 dur = collections.defaultdict(list)
 for r in trace('stats'):
-    dur[(short(r['Kernel_Name']), r['Grid_Size'], r['Workgroup_Size'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    grid = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+    wg = int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
+    dur[(short(r['Kernel_Name']), str(grid), str(wg))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 with open(os.path.join(out, 'r02_per_shape.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'grid_threads', 'workgroup', 'calls_per_step', 'avg_us', 'ms_per_step'])
