@@ -4,8 +4,9 @@
 // the current tap run (two LDS weight buffers, one barrier per tap), and the next chunk's halo is in flight in
 // registers during all taps of the current chunk.
 //
-// Tile: 128 consecutive output pixels (whole image rows; needs 128 % W == 0) x 32*TN output channels, 4 wave64,
-// each wave 32 pixels x 32*TN channels.  LDS rows are 128 B of channels + 16 B pad (bf16: 64 ch, fp32: 32 ch).
+// Tile: nrows whole image rows = nrows*W <= 128 consecutive output pixels (W a power of two: exactly 128; HRNet's 96 / 48 /
+// 24 / 12 / 6 wide maps: 96..126, the remaining MFMA rows idle) x 32*TN output channels, 4 wave64, each wave 32 pixels x
+// 32*TN channels.  LDS rows are 128 B of channels + 16 B pad (bf16: 64 ch, fp32: 32 ch).
 // Image-border rows are handled without branches in the MFMA loop: a lane whose tap row falls outside its image
 // reads its A fragment from a block of zero pixels; left/right borders are explicit zero columns in the halo.
 //
@@ -60,13 +61,19 @@ struct TapMma<float> {
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
+// tile geometry of one convolution: rows per tile and the multiply-high reciprocals of W and W*VPR (exact quotients for the
+// small indices divided here: v * d < 2^32)
+struct TileGeo { int nrows; unsigned mW, mWV; };
+__device__ __forceinline__ int qdiv(int v, unsigned magic) { return (int)__umulhi((unsigned)v, magic); }
+static inline unsigned magic_of(int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); }
+
 // One 128-pixel x 32*TN-channel tile of convolution `a`; (bx, by) = tile coordinates.  Shared by the single-conv
 // kernel and the pair kernel (two independent convolutions in one launch).
 // ALLW (3x3, one channel chunk, grids that do not fill the chip): the weights of ALL nine taps are staged up front, so the
 // MFMA loop runs its 9 taps back to back behind ONE barrier instead of one barrier (and one exposed weight-load latency) per
 // tap -- these launches are latency-bound, LDS capacity is not a constraint for them.
 template <typename T, int TN, int BK, bool ALLW = false>
-__device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int logW, const int dbg, const int bx, const int by) {
+__device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGeo geo, const int dbg, const int bx, const int by) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
     constexpr int LD = BK + 16 / (int)sizeof(T);
@@ -78,11 +85,12 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, pad = a.pad;
     const int M = a.N * H * W, GR = a.N * H;     // pixels, flattened (n,h) rows
-    const int nrows = 128 >> logW, hrows = nrows + R - 1, WP = W + R - 1;
+    const int nrows = geo.nrows, hrows = nrows + R - 1, WP = W + R - 1;
+    const int TPX = nrows * W;                   // output pixels of this tile (<= 128)
     const int zero_px = hrows * WP;              // 3 all-zero pixels behind the halo
     const int HP = zero_px + 3;
-    const int m0 = bx * 128, n0 = by * BNT;
-    const int g0 = m0 >> logW;
+    const int m0 = bx * TPX, n0 = by * BNT;
+    const int g0 = bx * nrows;
 
     // LDS: [BN tables | epilogue tables] then the tile region (halo + 2 weight buffers), which the epilogue reuses
     float* s_scale = reinterpret_cast<float*>(smem);
@@ -97,12 +105,12 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
 
     // ---- per-lane A addressing: output pixel -> halo row/col; invalid tap rows point at the zero pixels ----
     const int ml = wave * 32 + (lane & 31);
-    const int ti = ml >> logW, tj = ml & (W - 1);
+    const int ti = qdiv(ml, geo.mW), tj = ml - ti * W;
     int ab0, ab1, ab2;
     {
         const int g = g0 + ti;
         const int p = g % H;
-        const bool live = g < GR;
+        const bool live = g < GR && ml < TPX;
         if (R == 3) {
             ab0 = (live && p - 1 >= 0) ? ((ti + 0) * WP + tj) * LD : zero_px * LD;
             ab1 = live ? ((ti + 1) * WP + tj) * LD : zero_px * LD;
@@ -113,7 +121,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
     }
 
     // ---- staging registers ----
-    const int nvtot = (hrows << logW) * VPR;
+    const int nvtot = hrows * W * VPR;
+    const int WV = W * VPR;
     uint4 rh[NVH];
     unsigned hmask = 0;
     auto halo_load = [&](int c0) {
@@ -123,8 +132,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
             const int v = tid + i * 256;
             rh[i] = make_uint4(0, 0, 0, 0);
             if (v < nvtot) {
-                const int hr = v >> (logW + LOG_VPR);
-                const int rem = v & ((W << LOG_VPR) - 1);
+                const int hr = qdiv(v, geo.mWV);
+                const int rem = v - hr * WV;
                 const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
                 const int g = g0 - pad + hr;
                 if ((unsigned)g < (unsigned)GR) {
@@ -147,8 +156,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
         for (int i = 0; i < NVH; ++i) {
             const int v = tid + i * 256;
             if (v < nvtot) {
-                const int hr = v >> (logW + LOG_VPR);
-                const int j = (v & ((W << LOG_VPR) - 1)) >> LOG_VPR;
+                const int hr = qdiv(v, geo.mWV);
+                const int j = (v - hr * WV) >> LOG_VPR;
                 uint4 val = rh[i];
                 if (a.bn.mode != FPD_BN_NONE) {
                     float f[VEC];
@@ -268,25 +277,26 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const int lo
     }
     }
     if (dbg & 1) return;
+    const int Mlim = min(M, m0 + TPX);   // rows of the 128-row MFMA tile beyond the tile's pixels belong to the next tile
     if (K % VEC == 0) {
-        conv_epilogue_vec<T, TN>(a, acc, m0, n0, M, s_epi, stage, s_red);   // starts with a barrier
+        conv_epilogue_vec<T, TN>(a, acc, m0, n0, Mlim, s_epi, stage, s_red);   // starts with a barrier
     } else {
         __syncthreads();                 // every wave is done reading the tile region before s_red (aliased) is written
-        conv_epilogue<T, TN>(a, acc, m0 + wave * 32, n0, M, s_epi, s_red);
+        conv_epilogue<T, TN>(a, acc, m0 + wave * 32, n0, Mlim, s_epi, s_red);
     }
 }
 
 template <typename T, int TN, int BK, bool ALLW>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const int logW, const int dbg) {
-    conv_tile_body<T, TN, BK, ALLW>(a, logW, dbg, blockIdx.x, blockIdx.y);
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo, const int dbg) {
+    conv_tile_body<T, TN, BK, ALLW>(a, geo, dbg, blockIdx.x, blockIdx.y);
 }
 
 // Two INDEPENDENT convolutions with the same tile configuration in one launch: pixel tiles [0, nbx_a) belong to `a`,
 // the rest to `b` (block-uniform choice; the descriptors live in kernel-argument memory).  Used for the two parallel
 // bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
 template <typename T, int TN, int BK, bool ALLW>
-__global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const int logWa,
-                                                                const int logWb, const int nbx_a, const int dbg) {
+__global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const TileGeo logWa,
+                                                                const TileGeo logWb, const int nbx_a, const int dbg) {
     // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
     // launch ends with a's normal tail instead of a's tail followed by b's
     const int nbx_b = (int)gridDim.x - nbx_a;
@@ -305,13 +315,30 @@ static bool allw_ok(const fpd_conv_t& a, int blocks) {
     return a.R == 3 && a.C == BK && blocks <= allw_max_blocks();
 }
 
+constexpr size_t LDS_MAX = 160 * 1024;
+static int tile_rows(int W) { return std::max(1, 128 / W); }
+static int tiles_of(const fpd_conv_t& a) { return cdiv(a.N * a.H, tile_rows(a.W)); }
+template <typename T, int BK>
+static TileGeo make_geo(const fpd_conv_t& a) {
+    constexpr int VPR = BK / DT<T>::VEC;
+    TileGeo g;
+    g.nrows = tile_rows(a.W);
+    g.mW = magic_of(a.W);
+    g.mWV = magic_of(a.W * VPR);
+    return g;
+}
 template <typename T, int TN, int BK, bool ALLW>
-int launch_tile_v(const fpd_conv_t& a, int logW, hipStream_t st) {
+static size_t tile_lds(const fpd_conv_t& c) {
     constexpr int LD = BK + 16 / (int)sizeof(T);
-    const int nrows = 128 >> logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
-    const size_t tile = (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
+    const int hrows = tile_rows(c.W) + c.R - 1, WP = c.W + c.R - 1;
+    return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
+}
+
+template <typename T, int TN, int BK, bool ALLW>
+int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
-    const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile, epi);
+    const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
+    if (lds > LDS_MAX) return 1;
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>),
@@ -319,49 +346,49 @@ int launch_tile_v(const fpd_conv_t& a, int logW, hipStream_t st) {
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
-    const int M = a.N * a.H * a.W;
-    dim3 grid(cdiv(M, 128), cdiv(a.K, 32 * TN));
+    dim3 grid(tiles_of(a), cdiv(a.K, 32 * TN));
     static const int dbg = getenv("FPD_CONV_DBG") ? atoi(getenv("FPD_CONV_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, logW, dbg);
+    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, make_geo<T, BK>(a), dbg);
     return 0;
 }
 template <typename T, int TN, int BK>
-int launch_tile(const fpd_conv_t& a, int logW, hipStream_t st) {
+int launch_tile(const fpd_conv_t& a, hipStream_t st) {
     if constexpr (BK == 64 || (BK == 32 && sizeof(T) == 4)) {
-        if (allw_ok<T, BK>(a, cdiv(a.N * a.H * a.W, 128) * cdiv(a.K, 32 * TN))) return launch_tile_v<T, TN, BK, true>(a, logW, st);
+        if (allw_ok<T, BK>(a, tiles_of(a) * cdiv(a.K, 32 * TN))) {
+            const int rc = launch_tile_v<T, TN, BK, true>(a, st);
+            if (rc != 1) return rc;              // 1: the nine weight tiles do not fit the LDS next to the halo
+        }
     }
-    return launch_tile_v<T, TN, BK, false>(a, logW, st);
+    return launch_tile_v<T, TN, BK, false>(a, st);
 }
 
 template <typename T, int BK>
-int launch_tile_tn(const fpd_conv_t& a, int logW, hipStream_t st) {
-    const int mt = cdiv(a.N * a.H * a.W, 128);
+int launch_tile_tn(const fpd_conv_t& a, hipStream_t st) {
+    const int mt = tiles_of(a);
     int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
     while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;     // small layers: more, shorter blocks
-    if (tn == 4) return launch_tile<T, 4, BK>(a, logW, st);
-    if (tn == 2) return launch_tile<T, 2, BK>(a, logW, st);
-    return launch_tile<T, 1, BK>(a, logW, st);
+    if (tn == 4) return launch_tile<T, 4, BK>(a, st);
+    if (tn == 2) return launch_tile<T, 2, BK>(a, st);
+    return launch_tile<T, 1, BK>(a, st);
 }
 
+// shapes the halo-tile kernel covers: stride-1 "same" 1x1 / 3x3, rows of at most 128 pixels, C a multiple of 16
 static bool tile_domain(const fpd_conv_t& a) {
     if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2 || (a.W & (a.W - 1)) != 0) return false;
-    if (a.C % 16 != 0 || a.C > 256) return false;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2) return false;
+    if (a.C % 16 != 0 || a.C > FPD_MAXC) return false;
     if (a.epi == FPD_EPI_BNRELU_BWD && a.K > FPD_MAXC) return false;
     return true;
 }
-static int ilog2_rt(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
+// the halo of one channel chunk must fit the 8 staging vectors a thread holds
+static bool halo_fits(const fpd_conv_t& a, int vpr) { return (tile_rows(a.W) + a.R - 1) * a.W * vpr <= 2048; }
 
 template <typename T, int TN, int BK, bool ALLW>
 int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
-    constexpr int LD = BK + 16 / (int)sizeof(T);
-    const int la = ilog2_rt(a.W), lb = ilog2_rt(b.W);
-    auto tile_bytes = [&](const fpd_conv_t& c, int lw) {
-        const int hrows = (128 >> lw) + c.R - 1, WP = c.W + c.R - 1;
-        return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
-    };
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
-    const size_t lds = (size_t)(2 * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) + std::max({tile_bytes(a, la), tile_bytes(b, lb), epi});
+    const size_t lds = (size_t)(2 * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) +
+                       std::max({tile_lds<T, TN, BK, ALLW>(a), tile_lds<T, TN, BK, ALLW>(b), epi});
+    if (lds > LDS_MAX) return 1;
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>),
@@ -369,23 +396,26 @@ int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
-    const int nbx_a = cdiv(a.N * a.H * a.W, 128), nbx_b = cdiv(b.N * b.H * b.W, 128);
+    const int nbx_a = tiles_of(a), nbx_b = tiles_of(b);
     dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
-    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, la, lb, nbx_a, 0);
+    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a, 0);
     return 0;
 }
 template <typename T, int TN, int BK>
 int launch_pair(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     if constexpr (BK == 64 || (BK == 32 && sizeof(T) == 4)) {
-        const int blocks = (cdiv(a.N * a.H * a.W, 128) + cdiv(b.N * b.H * b.W, 128)) * cdiv(a.K, 32 * TN);
-        if (allw_ok<T, BK>(a, blocks)) return launch_pair_v<T, TN, BK, true>(a, b, st);
+        const int blocks = (tiles_of(a) + tiles_of(b)) * cdiv(a.K, 32 * TN);
+        if (allw_ok<T, BK>(a, blocks)) {
+            const int rc = launch_pair_v<T, TN, BK, true>(a, b, st);
+            if (rc != 1) return rc;
+        }
     }
     return launch_pair_v<T, TN, BK, false>(a, b, st);
 }
 
 template <typename T, int BK>
 int launch_pair_tn(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
-    const int mt = cdiv(a.N * a.H * a.W, 128) + cdiv(b.N * b.H * b.W, 128);
+    const int mt = tiles_of(a) + tiles_of(b);
     int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
     while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;
     if (tn == 4) return launch_pair<T, 4, BK>(a, b, st);
@@ -400,38 +430,31 @@ int launch_pair_tn(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
 int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     if (!tile_domain(a) || !tile_domain(b)) return 1;
     if (a.dtype != b.dtype || a.K != b.K || a.C != b.C || a.R != b.R) return 1;
-    const int nra = (128 >> ilog2_rt(a.W)) + a.R - 1, nrb = (128 >> ilog2_rt(b.W)) + b.R - 1;
     if (a.dtype == FPD_BF16) {
         const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
-        if (nra * a.W * (bk / 8) > 2048 || nrb * b.W * (bk / 8) > 2048) return 1;
+        if (!halo_fits(a, bk / 8) || !halo_fits(b, bk / 8)) return 1;
         if (bk == 64) return launch_pair_tn<bf16_t, 64>(a, b, st);
         if (bk == 32) return launch_pair_tn<bf16_t, 32>(a, b, st);
         return launch_pair_tn<bf16_t, 16>(a, b, st);
     }
     const int bk = (a.C % 32 == 0) ? 32 : 16;
-    if (nra * a.W * (bk / 4) > 2048 || nrb * b.W * (bk / 4) > 2048) return 1;
+    if (!halo_fits(a, bk / 4) || !halo_fits(b, bk / 4)) return 1;
     if (bk == 32) return launch_pair_tn<float, 32>(a, b, st);
     return launch_pair_tn<float, 16>(a, b, st);
 }
 
 // returns 1 when the shape is outside this kernel's domain (caller tries the generic MFMA kernel next)
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st) {
-    if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return 1;
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2 || (a.W & (a.W - 1)) != 0) return 1;
-    if (a.C % 16 != 0 || a.C > 256) return 1;
-    if (a.epi == FPD_EPI_BNRELU_BWD && a.K > FPD_MAXC) return 1;
-    int logW = 0;
-    while ((1 << logW) < a.W) ++logW;
-    const int hrows = (128 >> logW) + a.R - 1;
+    if (!tile_domain(a)) return 1;
     if (a.dtype == FPD_BF16) {
         const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
-        if (hrows * a.W * (bk / 8) > 2048) return 1;
-        if (bk == 64) return launch_tile_tn<bf16_t, 64>(a, logW, st);
-        if (bk == 32) return launch_tile_tn<bf16_t, 32>(a, logW, st);
-        return launch_tile_tn<bf16_t, 16>(a, logW, st);
+        if (!halo_fits(a, bk / 8)) return 1;
+        if (bk == 64) return launch_tile_tn<bf16_t, 64>(a, st);
+        if (bk == 32) return launch_tile_tn<bf16_t, 32>(a, st);
+        return launch_tile_tn<bf16_t, 16>(a, st);
     }
     const int bk = (a.C % 32 == 0) ? 32 : 16;
-    if (hrows * a.W * (bk / 4) > 2048) return 1;
-    if (bk == 32) return launch_tile_tn<float, 32>(a, logW, st);
-    return launch_tile_tn<float, 16>(a, logW, st);
+    if (!halo_fits(a, bk / 4)) return 1;
+    if (bk == 32) return launch_tile_tn<float, 32>(a, st);
+    return launch_tile_tn<float, 16>(a, st);
 }

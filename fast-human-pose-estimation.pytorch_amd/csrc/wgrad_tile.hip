@@ -311,6 +311,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     // 1x1 = 16 KB per block and HBM-bound -> enough blocks to keep every CU streaming
     int target = (a.R == 1) ? 256 : 128;
     if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
+    if (const char* e = getenv(a.R == 1 ? "FPD_WGRAD_BLOCKS_1" : "FPD_WGRAD_BLOCKS_3")) target = atoi(e);   // per filter size
     g.gx = std::max(1, std::min(g.mtiles, cdiv(target, g.gy)));
     const int nt = a.R * a.R * (cw / 32) * (cw / 32);
     g.slabs = g.gx * (nt <= 4 ? 2 : 1);          // KSPLIT kernels write one slab per wave group

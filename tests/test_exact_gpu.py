@@ -54,6 +54,8 @@ def exact_equal(bench, b, label):
 CONV = [  # N, H, W, C, K, R
     (2, 16, 16, 64, 64, 3), (1, 64, 64, 64, 64, 3), (3, 4, 4, 64, 64, 3), (5, 8, 8, 128, 128, 3), (2, 32, 32, 128, 64, 1),
     (2, 8, 8, 64, 128, 1), (1, 128, 128, 32, 32, 3), (2, 16, 16, 256, 16, 1), (2, 16, 16, 16, 256, 1), (1, 6, 5, 16, 32, 3),
+    # HRNet map widths (row tiles of 96 / 120 / 126 pixels, tiles straddling image boundaries)
+    (2, 32, 24, 64, 64, 3), (1, 64, 48, 32, 32, 3), (3, 8, 6, 128, 128, 3), (2, 16, 12, 64, 128, 1), (5, 7, 6, 384, 96, 3),
 ]
 
 
