@@ -48,7 +48,7 @@ struct WFrag<float> {
 };
 
 template <typename T, int R, int TP>
-__global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int logW, const int ctiles,
+__global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int nrows, const unsigned mW, const int ctiles,
                                                          const int mtiles, const int dbg) {
     using WF = WFrag<T>;
     constexpr int VEC = DT<T>::VEC;
@@ -63,8 +63,9 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, C = a.C, K = a.K, pad = a.pad;
     const int GR = a.N * H;
-    const int nrows = TP >> logW, hrows = nrows + R - 1, WP = W + R - 1;
-    const int HP = hrows * WP;
+    // a tile = nrows whole image rows = TPX <= TP pixels (W a power of two: TPX == TP; HRNet's 96- / 48-wide maps: 96 of 128)
+    const int hrows = nrows + R - 1, WP = W + R - 1;
+    const int HP = hrows * WP, TPX = nrows * W;
     const int kt = blockIdx.y / ctiles, ct = blockIdx.y - kt * ctiles;
     const int k0 = kt * CW, c0 = ct * CW;
     const int kn = min(CW, K - k0), cn = min(CW, C - c0);     // valid channels (multiples of VEC)
@@ -121,15 +122,15 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     constexpr int BPARTS = BLK / CW, BPIX = TP / BPARTS;
 
     // ---- staging: everything that does not depend on the pixel tile is computed once per thread ----
-    const int nvh = (hrows << logW) * vpr_c;          // halo vectors of one tile
-    const int nvd = TP * vpr_k;
+    const int nvh = hrows * W * vpr_c;                // halo vectors of one tile
+    const int nvd = TPX * vpr_k;
     int h_goff[NVH], h_loff[NVH], h_row[NVH];         // global element offset (tile 0), LDS element offset, halo row
     int d_goff[NVD], d_loff[NVD];
 #pragma unroll
     for (int i = 0; i < NVH; ++i) {
         const int v = tid + i * BLK;
         const int px = v / vpr_c, cv = (v - px * vpr_c) * VEC;
-        const int hr = px >> logW, j = px & (W - 1);
+        const int hr = px / W, j = px - hr * W;
         h_row[i] = (v < nvh) ? hr - pad : -(1 << 28);             // flattened row relative to the tile's first row
         h_goff[i] = ((hr - pad) * W + j) * C + c0 + cv;
         h_loff[i] = (hr * WP + j + pad) * LD + cv;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
         // one k-step = KSTEP pixels: operand fetch (transposing LDS reads) then NS MFMAs.  With many slots (3x3) the
         // MFMAs of a step cover the next step's LDS latency; with one slot (1x1) several steps are unrolled instead.
         auto kstep = [&](int pix0) {
-            const int ti = pix0 >> logW, j0 = pix0 & (W - 1);
+            const int ti = (int)__umulhi((unsigned)pix0, mW), j0 = pix0 - ti * W;      // k-steps never straddle rows (KSTEP | W)
             const int g = g0 + ti;
             const int p = g % H;
             const bool live = g < GR;                       // ragged last tile: rows past the tensor contribute zeros
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
         if (dbg & 2) continue;
         if (NS == 1) {
 #pragma unroll 4
-            for (int pix0 = (KSPLIT ? kgrp * KSTEP : 0); pix0 < TP; pix0 += (KSPLIT ? 2 : 1) * KSTEP) kstep(pix0);
+            for (int pix0 = (KSPLIT ? kgrp * KSTEP : 0); pix0 < TPX; pix0 += (KSPLIT ? 2 : 1) * KSTEP) kstep(pix0);
         } else {
 #pragma unroll 1
-            for (int pix0 = 0; pix0 < TP; pix0 += KSTEP) kstep(pix0);
+            for (int pix0 = 0; pix0 < TPX; pix0 += KSTEP) kstep(pix0);
         }
     }
 
@@ -290,21 +291,20 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     }
 }
 
-struct WtGrid { int logW, tp, gx, gy, ctiles, mtiles, slabs; };
+struct WtGrid { int nrows, tp, gx, gy, ctiles, mtiles, slabs; };
 
 // single source of truth for the launch geometry (also tells the caller how many partial slabs will be written)
 bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 16 || (a.W & (a.W - 1)) != 0) return false;
+    const int kstep = a.dtype == FPD_BF16 ? 16 : 2;          // pixels per MFMA k-step: a k-step must stay inside one image row
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 16 || a.W % kstep != 0) return false;
     if (a.C % 16 != 0 || a.K % 16 != 0) return false;
-    g.logW = 0;
-    while ((1 << g.logW) < a.W) ++g.logW;
     const int vec = a.dtype == FPD_BF16 ? 8 : 4, cw = a.dtype == FPD_BF16 ? 64 : 32;
-    const int hrows = (128 >> g.logW) + a.R - 1;
-    if (hrows * a.W * (std::min(a.C, cw) / vec) > 2048) return false;
     // 1x1: no halo, HBM-bound -> 256-pixel tiles double the bytes in flight per block and halve the barriers
     g.tp = (a.R == 1 && a.N * a.H * a.W >= 256 * 256 && 256 % a.W == 0) ? 256 : 128;
-    g.mtiles = cdiv(a.N * a.H * a.W, g.tp);
+    g.nrows = g.tp / a.W;
+    if ((g.nrows + a.R - 1) * a.W * (std::min(a.C, cw) / vec) > 2048) return false;
+    g.mtiles = cdiv(a.N * a.H, g.nrows);
     g.ctiles = cdiv(a.C, cw);
     g.gy = cdiv(a.K, cw) * g.ctiles;
     // persistent blocks, each flushing its whole accumulator once: 3x3 = 147 KB per block -> few blocks;
@@ -322,7 +322,7 @@ template <typename T, int R, int TP>
 int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     constexpr int CW = 128 / (int)sizeof(T);
     constexpr int LD = CW + 16 / (int)sizeof(T);
-    const int nrows = TP >> g.logW, hrows = nrows + a.R - 1, WP = a.W + a.R - 1;
+    const int hrows = g.nrows + a.R - 1, WP = a.W + a.R - 1;
     const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + TP + 16) * LD * sizeof(T);
     static size_t configured = 0;
     if (lds > configured) {
@@ -332,7 +332,8 @@ int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
         configured = lds;
     }
     static const int dbg = getenv("FPD_WGRAD_DBG") ? atoi(getenv("FPD_WGRAD_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.logW, g.ctiles, g.mtiles, dbg);
+    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
+                       (unsigned)((0x100000000ull / (unsigned long long)a.W) + 1ull), g.ctiles, g.mtiles, dbg);
     return 0;
 }
 

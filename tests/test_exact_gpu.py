@@ -105,7 +105,8 @@ def test_conv_pair_exact(case, dtype):
 @pytest.mark.parametrize('backend', [0, 1, 2, 'partials'])
 @pytest.mark.parametrize('dtype', [0, 1])
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 3), (4, 32, 32, 64, 64, 3), (2, 8, 8, 128, 64, 1), (32, 4, 4, 64, 64, 3),
-                                  (1, 64, 64, 64, 128, 1), (2, 64, 64, 64, 64, 3)])
+                                  (1, 64, 64, 64, 128, 1), (2, 64, 64, 64, 64, 3), (2, 64, 48, 32, 32, 3), (3, 16, 48, 64, 64, 1),
+                                  (2, 32, 24, 64, 64, 3)])
 def test_conv_wgrad_exact(case, dtype, backend):
     """dw = sum over pixels of dy (x) x over sparse small-integer planes: integer sums far below 2^24 -> exact in fp32."""
     N, H, W, C, K, Rr = case

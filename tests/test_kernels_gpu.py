@@ -209,7 +209,8 @@ def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
 
 WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), (1, 9, 7, 16, 16, 3, 1, False),
                (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True),
-               (32, 4, 4, 64, 64, 3, 1, True), (32, 8, 8, 64, 64, 3, 1, True), (32, 4, 4, 128, 64, 1, 0, True)]   # deepest hourglass levels
+               (32, 4, 4, 64, 64, 3, 1, True), (32, 8, 8, 64, 64, 3, 1, True), (32, 4, 4, 128, 64, 1, 0, True),   # deepest hourglass levels
+               (2, 16, 48, 32, 64, 3, 1, True), (3, 32, 24, 64, 64, 3, 1, True), (2, 64, 48, 32, 32, 1, 0, False)]   # HRNet map widths
 
 
 @pytest.mark.parametrize('backend', BACKENDS + ['partials'])
@@ -234,7 +235,7 @@ def test_conv_wgrad(case, dtype, backend):
     op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
     if backend == 'partials':          # default dispatch with the two-stage (slab + reduce) flush instead of atomics
         bt.realise().run([op], 0, partials=True)
-        assert bt.n_partial_ops == (1 if W >= 16 and (W & (W - 1)) == 0 else 0)
+        assert bt.n_partial_ops == (1 if W >= 16 and W % (16 if dtype == 1 else 2) == 0 else 0)    # row tiles: k-steps stay in a row
     else:
         bt.realise().run([op], backend)
     m = N * P * Q
