@@ -127,6 +127,26 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     }
     const float relu_gate = a.epi_bn.relu ? 0.f : -3.4e38f;     // z > gate keeps the gradient
     const int col_l = lane & 31, rhalf = lane >> 5;
+    // The rows a thread owns are processed in groups of G: the residual / epi_x vectors of a whole group are requested
+    // together (one memory latency per group instead of one per row -- these launches are latency-bound), and the first
+    // group's requests go out BEFORE the accumulators travel through the LDS staging tile.
+    constexpr int NR = 128 / RSTEP, G = NR < 4 ? NR : 4, NG = NR / G;
+    static_assert(NR % G == 0, "row groups");
+    uint4 rres[G], rex[G];
+    auto request = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int m = m0 + row0 + (g * G + i) * RSTEP;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            rex[i] = make_uint4(0, 0, 0, 0);
+            if (m < M && kok) {
+                const size_t off = (size_t)m * K + k0;
+                if (res != nullptr) rres[i] = *reinterpret_cast<const uint4*>(res + off);
+                if (bwd) rex[i] = *reinterpret_cast<const uint4*>(ex + off);
+            }
+        }
+    };
+    request(0);
     __syncthreads();                                       // tile region free: every wave is past its last MFMA LDS read
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -136,8 +156,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
         }
     __syncthreads();
-    {
-        for (int row = row0; row < 128; row += RSTEP) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g > 0) request(g);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int row = row0 + (g * G + i) * RSTEP;
             const int m = m0 + row;
             if (m < M && kok) {
                 float v[VEC];
@@ -149,7 +173,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 const size_t off = (size_t)m * K + k0;
                 if (res != nullptr) {
                     float r[VEC];
-                    DT<T>::unpack(*reinterpret_cast<const uint4*>(res + off), r);
+                    DT<T>::unpack(rres[i], r);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v[e] += r[e];
                 }
@@ -158,7 +182,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 const uint4 packed = DT<T>::pack(v);
                 if (bwd) {
                     float xv[VEC], vr[VEC];
-                    DT<T>::unpack(*reinterpret_cast<const uint4*>(ex + off), xv);
+                    DT<T>::unpack(rex[i], xv);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const float z = fmaf(xv[e], esc[e], esh[e]);

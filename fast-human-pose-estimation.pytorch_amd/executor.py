@@ -332,7 +332,10 @@ class GraphInstance:
         self.lanes_enabled = os.environ.get('FPD_LANES', '1') != '0'
         self.schedules = {}
         # several lanes in flight: do not hand a released block to the very next tensor (false WAR dependencies)
+        # (a frozen graph has a single lane: immediate reuse keeps its working set small -- FPD_REUSE_DELAY_EVAL to experiment)
         delay = int(os.environ.get('FPD_REUSE_DELAY', '400')) if self.lanes_enabled else 0
+        if not self.train:
+            delay = int(os.environ.get('FPD_REUSE_DELAY_EVAL', '0'))
         act = G.plan_memory(ops, reuse_delay=delay)
         self.act_elems = act
         self.A.alloc('act', act)
