@@ -15,6 +15,11 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
 int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st);
+int fpd_flip_w_launch(const float* x, float* y, int64_t rows, int W, hipStream_t st);
+int fpd_flip_merge_launch(const fpd_flipmerge_t& p, hipStream_t st);
+int fpd_final_preds_launch(const fpd_finalpreds_t& p, hipStream_t st);
+int fpd_render_targets_launch(const fpd_targets_t& a, hipStream_t st);
+int fpd_warp_affine_launch(const fpd_warp_t& a, hipStream_t st);
 int fpd_head_fused_launch(const fpd_head_t& a, hipStream_t st);
 int fpd_head_fold_launch(const fpd_head_t& a, float* out, hipStream_t st);
 int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st);
@@ -79,6 +84,7 @@ int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
     SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t); SZ(fpd_head_t); SZ(fpd_affsum_t); SZ(fpd_layout_t);
+    SZ(fpd_flipmerge_t); SZ(fpd_finalpreds_t); SZ(fpd_targets_t); SZ(fpd_warp_src_t); SZ(fpd_warp_t);
 #undef SZ
     return -1;
 }
@@ -269,6 +275,41 @@ int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->B > 0 && a->J > 0 && a->H > 0 && a->W > 0 && a->log_slots > 0, "pck: bad dims");
     FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "pck: bad dtype %d", a->dtype);
     int rc = fpd_pck_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_flip_w(const float* x, float* y, int64_t rows, int32_t W, fpd_stream_t stream) {
+    FPD_REQUIRE(x && y && x != y, "flip_w: null or aliased pointer");
+    FPD_REQUIRE(rows > 0 && W > 0, "flip_w: bad dims");
+    int rc = fpd_flip_w_launch(x, y, rows, W, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_flip_merge(const fpd_flipmerge_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->b && a->y && a->b != a->y, "flip_merge: null or aliased pointer");
+    FPD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->J > 0 && a->J <= FPD_MAX_JOINTS, "flip_merge: bad dims (J <= %d)", FPD_MAX_JOINTS);
+    for (int j = 0; j < a->J; ++j) FPD_REQUIRE(a->src[j] >= 0 && a->src[j] < a->J, "flip_merge: src[%d] = %d out of range", j, a->src[j]);
+    int rc = fpd_flip_merge_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_final_preds(const fpd_finalpreds_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->hm && a->coords && a->maxvals, "final_preds: null pointer");
+    FPD_REQUIRE((a->trans == nullptr) == (a->preds == nullptr), "final_preds: trans and preds go together");
+    FPD_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->J > 0, "final_preds: bad dims");
+    int rc = fpd_final_preds_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_render_targets(const fpd_targets_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->joints && a->vis && a->g && a->target && a->weight, "render_targets: null pointer");
+    FPD_REQUIRE(a->B > 0 && a->J > 0 && a->H > 0 && a->W > 0 && a->patch > 0 && (a->patch & 1), "render_targets: bad dims");
+    FPD_REQUIRE(a->stride_x > 0 && a->stride_y > 0, "render_targets: bad stride");
+    int rc = fpd_render_targets_launch(*a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+int fpd_warp_affine(const fpd_warp_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a && a->src && a->out, "warp_affine: null pointer");
+    FPD_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "warp_affine: bad dims");
+    for (int c = 0; c < 3; ++c) FPD_REQUIRE(a->std[c] != 0.f, "warp_affine: std[%d] == 0", c);
+    int rc = fpd_warp_affine_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
 

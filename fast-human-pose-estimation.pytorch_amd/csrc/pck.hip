@@ -9,27 +9,10 @@
 //                 function.py:150-152 without a host sync); counts are zeroed for the next iteration
 // Index work is bit-exact with the reference, quirk included: evaluate.py:55 builds the normaliser as [h, w]/10 and
 // applies it to (x, y), i.e. x is divided by h/10 and y by w/10 (identical for square maps, different at 64x48).
+#include "argmax.h"
 #include "common.h"
 
 namespace {
-
-struct ArgMax { float v; int i; };
-__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
-__device__ __forceinline__ ArgMax block_argmax(ArgMax m, ArgMax* s) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax t;
-        t.v = __shfl_xor(m.v, o, 64);
-        t.i = __shfl_xor(m.i, o, 64);
-        m = better(m, t);
-    }
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
-    __syncthreads();
-    ArgMax r = s[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = better(r, s[w]);
-    __syncthreads();
-    return r;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void pck_kernel(const fpd_pck_t a) {

@@ -76,7 +76,8 @@ def _defaults():
                   'TARGET_TYPE': 'gaussian', 'IMAGE_SIZE': [256, 256], 'HEATMAP_SIZE': [64, 64], 'SIGMA': 2, 'DTYPE': 'fp32',
                   'EXTRA': {'NUM_FEATURES': 256, 'NUM_STACKS': 8, 'NUM_BLOCKS': 1}},
         'LOSS': {'USE_OHKM': False, 'TOPK': 8, 'USE_TARGET_WEIGHT': True, 'USE_DIFFERENT_JOINTS_WEIGHT': False},
-        'DATASET': {'ROOT': '', 'DATASET': 'synthetic', 'TRAIN_SET': 'train', 'TEST_SET': 'valid', 'NUM_SAMPLES': 256},
+        'DATASET': {'ROOT': '', 'DATASET': 'synthetic', 'TRAIN_SET': 'train', 'TEST_SET': 'valid', 'NUM_SAMPLES': 256,
+                    'NUM_VALID_SAMPLES': 64},
         'TRAIN': {'LR_FACTOR': 0.1, 'LR_STEP': [90, 120], 'LR': 0.00025, 'OPTIMIZER': 'adam', 'MOMENTUM': 0.9, 'WD': 0.0001,
                   'NESTEROV': False, 'GAMMA1': 0.99, 'GAMMA2': 0.0, 'BEGIN_EPOCH': 0, 'END_EPOCH': 140, 'RESUME': False,
                   'CHECKPOINT': '', 'BATCH_SIZE_PER_GPU': 32, 'SHUFFLE': True},

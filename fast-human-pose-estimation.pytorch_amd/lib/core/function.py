@@ -169,3 +169,103 @@ def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, 
     """function.py:28-96: plain (non-distillation) training = the same fused step without a teacher graph (alpha 0)."""
     use_w = _check_supported(optimizer, criterion, criterion)
     return _run_epoch(config, train_loader, model, None, use_w, optimizer, epoch, writer_dict, allreduce, world_size, 0.0)['loss']
+
+
+def _to_numpy(v):
+    return v.numpy() if torch.is_tensor(v) else __import__('numpy').asarray(v)
+
+
+def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, writer_dict=None):
+    """function.py:189-332 with the reference's signature and return value (the dataset's perf indicator).
+
+    Per batch: eval-mode forward (the folded-BN plan: fused frozen Bottlenecks / heads in bf16, the parity kernels in
+    fp32), TEST.FLIP_TEST second forward on the width-flipped batch, flip_back + TEST.SHIFT_HEATMAP shift + average
+    (one kernel), JointsMSELoss, PCK accuracy (csrc/pck.hip), and get_final_preds (arg-max, TEST.POST_PROCESS
+    quarter-pixel shift, affine map to image coordinates: one kernel).  The reference moves every one of these tensors
+    to the host and back (np.flip / flip_back / accuracy / get_final_preds are numpy); here only the final
+    [N,J,2]+[N,J,1] predictions and two scalars per batch cross PCIe.  The result arrays handed to
+    `val_dataset.evaluate(...)` have the reference's layout (all_preds [num,J,3], all_boxes [num,6])."""
+    import numpy as np
+
+    from ..utils.transforms import flip_input, flip_merge, get_affine_transform
+    from .evaluate import DeviceAccuracy
+    from .inference import final_preds_device
+    batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    net = _unwrap(model)
+    dev = net._flat['param'].device
+    num_samples = len(val_dataset)
+    all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)
+    all_boxes = np.zeros((num_samples, 6))
+    image_path, filenames, imgnums = [], [], []
+    idx = 0
+    metric = None
+    with torch.no_grad():
+        end = time.time()
+        for i, (inp, target, target_weight, meta) in enumerate(val_loader):
+            inp = inp.to(dev, non_blocking=True)
+            outputs = model(inp)
+            output = outputs[-1] if isinstance(outputs, list) else outputs
+            if config.TEST.FLIP_TEST:
+                outputs_flipped = model(flip_input(inp))
+                output_flipped = outputs_flipped[-1] if isinstance(outputs_flipped, list) else outputs_flipped
+                output = flip_merge(output, output_flipped, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)
+            target = target.to(dev, non_blocking=True)
+            target_weight = target_weight.to(dev, non_blocking=True)
+            loss = criterion(output, target, target_weight)
+            num_images = inp.size(0)
+            n, j, h, w = output.shape
+            # accuracy(output, target) on the device: NHWC copy of the merged map -> pck kernels -> log ring
+            if metric is None or metric.args.B != n:
+                metric = DeviceAccuracy(n, j, h, w, R.F32, dev, slots=16)
+                nhwc = torch.empty((n, h, w, j), dtype=torch.float32, device=dev)
+            R.check(R.lib().fpd_nchw_to_nhwc(output.data_ptr(), nhwc.data_ptr(), n, j, h, w, R.F32, R.current_stream()))
+            tgt = target.float().contiguous()
+            metric.bind(nhwc.data_ptr(), tgt.data_ptr()).enqueue()
+            c, s = _to_numpy(meta['center']), _to_numpy(meta['scale'])
+            score = _to_numpy(meta['score'])
+            trans = np.stack([get_affine_transform(c[k], s[k], 0, [w, h], inv=1) for k in range(n)])
+            _, preds, maxvals = final_preds_device(output, torch.from_numpy(trans).to(dev), config.TEST.POST_PROCESS)
+            # the one synchronisation of the iteration: results + the two scalars
+            preds, maxvals = preds.cpu().numpy(), maxvals.cpu().numpy()
+            losses.update(loss.item(), num_images)
+            (avg_acc, cnt), = metric.drain()
+            acc.update(avg_acc, cnt)
+            batch_time.update(time.time() - end)
+            end = time.time()
+            all_preds[idx:idx + num_images, :, 0:2] = preds[:, :, 0:2]
+            all_preds[idx:idx + num_images, :, 2:3] = maxvals
+            all_boxes[idx:idx + num_images, 0:2] = c[:, 0:2]
+            all_boxes[idx:idx + num_images, 2:4] = s[:, 0:2]
+            all_boxes[idx:idx + num_images, 4] = np.prod(s * 200, 1)
+            all_boxes[idx:idx + num_images, 5] = score
+            image_path.extend(meta['image'])
+            idx += num_images
+            if i % config.PRINT_FREQ == 0:
+                logger.info('Test: [{0}/{1}]\t'
+                            'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                            'Loss {loss.val:.4f} ({loss.avg:.4f})\t'
+                            'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(i, len(val_loader), batch_time=batch_time,
+                                                                             loss=losses, acc=acc))
+        name_values, perf_indicator = val_dataset.evaluate(config, all_preds, output_dir, all_boxes, image_path,
+                                                           filenames, imgnums)
+        for nv in (name_values if isinstance(name_values, list) else [name_values]):
+            _print_name_value(nv, config.MODEL.NAME)
+        if writer_dict and writer_dict.get('writer') is not None:
+            writer, gs = writer_dict['writer'], writer_dict['valid_global_steps']
+            writer.add_scalar('valid_loss', losses.avg, gs)
+            writer.add_scalar('valid_acc', acc.avg, gs)
+            for nv in (name_values if isinstance(name_values, list) else [name_values]):
+                writer.add_scalars('valid', dict(nv), gs)
+            writer_dict['valid_global_steps'] = gs + 1
+    validate.last = {'loss': losses.avg, 'acc': acc.avg, 'all_preds': all_preds, 'all_boxes': all_boxes}
+    return perf_indicator
+
+
+def _print_name_value(name_value, full_arch_name):
+    """function.py:335-353: markdown table of the dataset's metrics."""
+    names, values = list(name_value.keys()), list(name_value.values())
+    logger.info('| Arch ' + ' '.join('| {}'.format(n) for n in names) + ' |')
+    logger.info('|---' * (len(names) + 1) + '|')
+    arch = full_arch_name if len(full_arch_name) <= 15 else full_arch_name[:8] + '...'
+    logger.info('| ' + arch + ' ' + ' '.join('| {:.3f}'.format(v) for v in values) + ' |')

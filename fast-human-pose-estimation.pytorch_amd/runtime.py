@@ -98,6 +98,30 @@ class PckT(C.Structure):
                 ('_pad', _i32), ('out', _vp), ('target', _vp), ('counts', _vp), ('log', _vp), ('cursor', _vp), ('losses', _vp)]
 
 
+class FlipMergeT(C.Structure):
+    _fields_ = [('N', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('shift', _i32), ('_pad', _i32), ('a', _vp), ('b', _vp),
+                ('y', _vp), ('src', _i32 * 32)]
+
+
+class FinalPredsT(C.Structure):
+    _fields_ = [('N', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('post_process', _i32), ('_pad', _i32), ('hm', _vp),
+                ('trans', _vp), ('coords', _vp), ('preds', _vp), ('maxvals', _vp)]
+
+
+class TargetsT(C.Structure):
+    _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('patch', _i32), ('_pad', _i32), ('stride_x', _f64),
+                ('stride_y', _f64), ('joints', _vp), ('vis', _vp), ('g', _vp), ('target', _vp), ('weight', _vp)]
+
+
+class WarpSrcT(C.Structure):
+    _fields_ = [('img', _vp), ('h', _i32), ('w', _i32), ('row_bytes', _i64), ('minv', _f64 * 6)]
+
+
+class WarpT(C.Structure):
+    _fields_ = [('B', _i32), ('H', _i32), ('W', _i32), ('_pad', _i32), ('src', _vp), ('mean', _f32 * 3), ('std', _f32 * 3),
+                ('out', _vp)]
+
+
 class LossT(C.Structure):
     _fields_ = [('B', _i32), ('J', _i32), ('H', _i32), ('W', _i32), ('S', _i32), ('dtype', _i32),
                 ('target_nchw', _i32), ('alpha', _f32), ('out', _vp * MAX_STACKS), ('dout', _vp * MAX_STACKS),
@@ -135,7 +159,9 @@ class TableT(C.Structure):
 _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_stem_t': StemT, 'fpd_ew_t': EwT,
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
-            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT, 'fpd_affsum_t': AffsumT, 'fpd_layout_t': LayoutT}
+            'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT, 'fpd_affsum_t': AffsumT, 'fpd_layout_t': LayoutT,
+            'fpd_flipmerge_t': FlipMergeT, 'fpd_finalpreds_t': FinalPredsT, 'fpd_targets_t': TargetsT,
+            'fpd_warp_src_t': WarpSrcT, 'fpd_warp_t': WarpT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -153,6 +179,11 @@ SYMBOLS = {
     'fpd_elementwise_pair': (C.c_int, [C.POINTER(EwPairT), _vp]),
     'fpd_pck': (C.c_int, [C.POINTER(PckT), _vp]),
     'fpd_affsum': (C.c_int, [C.POINTER(AffsumT), _vp]),
+    'fpd_flip_w': (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    'fpd_flip_merge': (C.c_int, [C.POINTER(FlipMergeT), _vp]),
+    'fpd_final_preds': (C.c_int, [C.POINTER(FinalPredsT), _vp]),
+    'fpd_render_targets': (C.c_int, [C.POINTER(TargetsT), _vp]),
+    'fpd_warp_affine': (C.c_int, [C.POINTER(WarpT), _vp]),
     'fpd_head_forward': (C.c_int, [C.POINTER(HeadT), _vp]),
     'fpd_head_fold': (C.c_int, [C.POINTER(HeadT), _vp]),
     'fpd_loss': (C.c_int, [C.POINTER(LossT), _vp]),

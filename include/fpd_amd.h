@@ -325,6 +325,83 @@ typedef struct {
 } fpd_pck_t;
 int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream);
 
+/* ---- validate / flip-test post-processing (lib/core/function.py:189-332) ---- */
+/* y[r][c] = x[r][W-1-c] for `rows` rows of W floats: the flipped input image of the flip test
+ * (function.py:217-221: np.flip(input.cpu().numpy(), 3)); x is [N,3,H,W] fp32, rows = N*3*H. */
+int fpd_flip_w(const float* x, float* y, int64_t rows, int32_t W, fpd_stream_t stream);
+
+/* flip_back (lib/utils/transforms.py:15-29) + the one-pixel shift of the flipped map (function.py:233-236,
+ * TEST.SHIFT_HEATMAP) + the average (function.py:238) in one pass over fp32 [N,J,H,W] maps:
+ *   f[n,j,y,x]  = b[n, src[j], y, W-1-x]               (width reversed, left/right joint channels swapped)
+ *   f'[.., x]   = shift && x >= 1 ? f[.., x-1] : f[.., x]
+ *   y           = (a + f') * 0.5f
+ * src[j] is the channel of b that lands in channel j after flip_back's sequential pair swaps. */
+#define FPD_MAX_JOINTS 32
+typedef struct {
+    int32_t N, J, H, W;
+    int32_t shift, _pad;
+    const float* a;        /* [N,J,H,W] model(input)[-1]; NULL: y = f' (flip_back + shift only, no average) */
+    const float* b;        /* [N,J,H,W] model(flipped input)[-1] */
+    float* y;              /* [N,J,H,W] (may alias a, not b) */
+    int32_t src[FPD_MAX_JOINTS];
+} fpd_flipmerge_t;
+int fpd_flip_merge(const fpd_flipmerge_t* a, fpd_stream_t stream);
+
+/* get_final_preds (lib/core/inference.py:49-79): per (sample, joint) the heat-map arg-max (first maximum wins;
+ * coordinates zeroed where the maximum is not positive, inference.py:18-46), the quarter-pixel shift towards the higher
+ * neighbour when post_process (TEST.POST_PROCESS, inference.py:57-70) and transform_preds (lib/utils/transforms.py:50-55):
+ * preds = trans[n] . [x, y, 1] in float64, stored as float32.  trans[n] is the 2x3 inverse affine of sample n
+ * (get_affine_transform(center, scale, 0, [W, H], inv=1), transforms.py:57-92 -- six doubles per sample computed by
+ * the caller); trans/preds NULL = heat-map coordinates only. */
+typedef struct {
+    int32_t N, J, H, W;
+    int32_t post_process, _pad;
+    const float* hm;       /* [N,J,H,W] fp32 */
+    const double* trans;   /* [N][2][3] or NULL */
+    float* coords;         /* [N,J,2] heat-map coordinates (x, y) after post-processing */
+    float* preds;          /* [N,J,2] image coordinates, or NULL */
+    float* maxvals;        /* [N,J] */
+} fpd_finalpreds_t;
+int fpd_final_preds(const fpd_finalpreds_t* a, fpd_stream_t stream);
+
+/* ---- device data pipeline (lib/dataset/JointsDataset.py:113-198,233-289) ---- */
+/* generate_target (JointsDataset.py:233-289) for a batch: Gaussian heat-map targets + target weights from joint
+ * positions in network-input pixels.  mu = int(joint / feat_stride + 0.5) in float64 (feat_stride = image/heat-map size),
+ * the (6*sigma+1)^2 patch `g` (built once by the caller with the reference's float32 numpy expression, so the values are
+ * the reference's bit for bit) is pasted clipped at the border when weight > 0.5; weight = 0 when the patch lies fully
+ * outside.  Index work is bit-exact with the reference. */
+typedef struct {
+    int32_t B, J, H, W;            /* heat-map shape */
+    int32_t patch, _pad;           /* patch edge = 6*sigma + 1 */
+    double stride_x, stride_y;     /* image_size / heatmap_size */
+    const double* joints;          /* [B,J,3] (x, y, -) in network-input pixels */
+    const float* vis;              /* [B,J] joints_vis[:, 0] */
+    const float* g;                /* [patch][patch] */
+    float* target;                 /* [B,J,H,W] */
+    float* weight;                 /* [B,J] */
+} fpd_targets_t;
+int fpd_render_targets(const fpd_targets_t* a, fpd_stream_t stream);
+
+/* The crop of JointsDataset.__getitem__ (:160-168) for a batch: cv2.warpAffine(img, trans, (W,H), INTER_LINEAR)
+ * (constant zero border) -> ToTensor (/255, HWC->CHW) -> Normalize(mean, std) (tools/fpd_train.py:182-193), one pass,
+ * reading interleaved 8-bit source images that differ in size.  The bilinear sample follows OpenCV's fixed-point scheme
+ * (source coordinates in 1/32 pixel from 10-bit fixed-point row/column terms, 15-bit weights, 8-bit rounded result)
+ * so that the 8-bit intermediate matches cv2's; `minv` is the DST->SRC map (the inverse of get_affine_transform's
+ * matrix, what cv2.warpAffine computes internally with invertAffineTransform). */
+typedef struct {
+    const uint8_t* img;            /* [h][w][3] interleaved */
+    int32_t h, w;
+    int64_t row_bytes;
+    double minv[6];
+} fpd_warp_src_t;
+typedef struct {
+    int32_t B, H, W, _pad;         /* output [B,3,H,W] fp32 */
+    const fpd_warp_src_t* src;     /* device table [B] */
+    float mean[3], std[3];         /* ToTensor + Normalize in torch's fp32 order: (u8 / 255.f - mean) / std, per SOURCE channel */
+    float* out;
+} fpd_warp_t;
+int fpd_warp_affine(const fpd_warp_t* a, fpd_stream_t stream);
+
 /* ---- execution plan: a recorded list of the ops above, replayed with one call ---- */
 enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,

@@ -27,7 +27,8 @@ import torch.utils.data  # noqa: E402
 from fpd_amd import dist as fdist, executor as E, synth  # noqa: E402
 from fpd_amd.lib import models  # noqa: E402,F401
 from fpd_amd.lib.config import cfg, update_config  # noqa: E402
-from fpd_amd.lib.core.function import fpd_train, train  # noqa: E402
+from fpd_amd.lib.core.function import fpd_train, train, validate  # noqa: E402
+from fpd_amd.lib.dataset import SyntheticPose  # noqa: E402
 from fpd_amd.lib.core.loss import JointsMSELoss  # noqa: E402
 from fpd_amd.lib.utils.utils import (get_model_summary, get_optimizer, load_checkpoint, multistep_lr,  # noqa: E402
                                      save_checkpoint)
@@ -43,30 +44,6 @@ def parse_args():
     p.add_argument('--dataDir', default='', type=str)
     p.add_argument('--max-iters', type=int, default=0, help='stop every epoch after this many iterations (smoke runs)')
     return p.parse_args()
-
-
-class SyntheticPose(torch.utils.data.Dataset):
-    """Seeded synthetic samples shaped like JointsDataset.__getitem__ (lib/dataset/JointsDataset.py:113-198)."""
-
-    POOL = 256          # distinct samples generated up front (one vectorised call); indices wrap around the pool
-
-    def __init__(self, cfg, n, seed):
-        self.n, self.seed = n, seed
-        self.joints = cfg.MODEL.NUM_JOINTS
-        self.image, self.heat, self.sigma = tuple(cfg.MODEL.IMAGE_SIZE), tuple(cfg.MODEL.HEATMAP_SIZE), cfg.MODEL.SIGMA
-        self.pool = synth.make_batch(seed * 1000003, min(n, self.POOL), self.joints, self.image, self.heat, self.sigma)
-
-    def __len__(self):
-        return self.n
-
-    def __getitem__(self, i):
-        return i
-
-    def collate(self, idx):
-        """One gather per tensor instead of default_collate's stack of 32 samples (48 ms per batch on one core)."""
-        x, t, w = self.pool
-        k = torch.as_tensor(idx) % x.shape[0]
-        return x[k], t[k], w[k], {'index': torch.as_tensor(idx)}
 
 
 def get_train_type(train_type, checkpoint):
@@ -132,6 +109,9 @@ def main():
     train_set = SyntheticPose(cfg, cfg.DATASET.NUM_SAMPLES, seed=rank)
     loader = torch.utils.data.DataLoader(train_set, batch_size=bs, shuffle=cfg.TRAIN.SHUFFLE, num_workers=0,
                                          pin_memory=cfg.PIN_MEMORY, drop_last=True, collate_fn=train_set.collate)
+    valid_set = SyntheticPose(cfg, cfg.DATASET.NUM_VALID_SAMPLES, seed=10007)
+    valid_loader = torch.utils.data.DataLoader(valid_set, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU, shuffle=False, num_workers=0,
+                                               pin_memory=cfg.PIN_MEMORY, collate_fn=valid_set.collate)
     if args.max_iters:
         import itertools
         full = loader
@@ -178,9 +158,13 @@ def main():
         logger.info('=> epoch %d done in %.1fs, %.1f samples/s, last logged loss %.5f', epoch, time.time() - t0,
                     len(loader) * bs * world / max(time.time() - t0, 1e-9), loss)
         if rank == 0:
+            # :266-285: evaluate on the validation set (flip test etc. per cfg.TEST), keep the best model
+            perf_indicator = validate(cfg, valid_loader, valid_set, model, pose_criterion, out_dir, cfg.LOG_DIR, writer_dict)
+            best_model = perf_indicator >= best_perf
+            best_perf = max(best_perf, perf_indicator)
             save_checkpoint({'epoch': epoch + 1, 'model': cfg.MODEL.NAME, 'state_dict': model.state_dict(),
-                             'best_state_dict': model.module.state_dict(), 'perf': -loss,
-                             'optimizer': optimizer.state_dict()}, True, out_dir)
+                             'best_state_dict': model.module.state_dict(), 'perf': perf_indicator,
+                             'optimizer': optimizer.state_dict()}, best_model, out_dir)
     if rank == 0:
         torch.save(model.module.state_dict(), os.path.join(out_dir, 'final_state.pth'))      # :288-294
     if world > 1:
