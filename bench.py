@@ -32,7 +32,7 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
-GFLOP_PER_IMAGE = {'hg4x128<-hg8x256': 79.478, 'w32<-w48@256x192': 77.211}       # SURVEY.md section 8(d), conv 2*MAC: t-fwd + s-fwd + s-bwd
+GFLOP_PER_IMAGE = {'hg4x128<-hg8x256': 79.478, 'w32<-w48@256x192': 77.211, 'w32<-w48@384x288': 173.725}       # SURVEY.md section 8(d), conv 2*MAC: t-fwd + s-fwd + s-bwd
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}          # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
@@ -220,9 +220,10 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--backend', default='mfma', choices=['mfma', 'naive'])
-    ap.add_argument('--config', default='hourglass', choices=['hourglass', 'hrnet'],
+    ap.add_argument('--config', default='hourglass', choices=['hourglass', 'hrnet', 'hrnet_fp8'],
                     help="hourglass = BASELINE configs[1] (the headline metric); hrnet = configs[3] shapes: HRNet-W32 student + "
-                         "HRNet-W48 teacher, 256x192, J=17 (secondary line: step-level roofline only)")
+                         "HRNet-W48 teacher, 256x192, J=17; hrnet_fp8 = configs[4] shapes: the same pair at 384x288 with the "
+                         "student's forward convolutions on the fp8 matrix pipe (secondary lines: step-level roofline only)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-fp32-build parity sub-object')
     ap.add_argument('--graphs', action='store_true',
@@ -258,19 +259,21 @@ def main():
     R.lib()
     R.set_backend(R.BACKEND_NAIVE if args.backend == 'naive' else R.BACKEND_MFMA)
 
-    hr = args.config == 'hrnet'
-    B, J, H, W = (args.batch, 17, 256, 192) if hr else (args.batch, 16, 256, 256)
+    hr = args.config in ('hrnet', 'hrnet_fp8')
+    f8 = args.config == 'hrnet_fp8'
+    B, J, H, W = (args.batch, 17, 384, 288) if f8 else ((args.batch, 17, 256, 192) if hr else (args.batch, 16, 256, 256))
     torch.manual_seed(1)                       # identical weights on every rank
     if hr:
         from fpd_amd.lib.config import _wrap
         from fpd_amd.lib.models import pose_hrnet
 
-        def hr_cfg(w):
+        def hr_cfg(w, weight_dtype=''):
             st = lambda n, m: dict(NUM_MODULES=m, NUM_BRANCHES=n, BLOCK='BASIC', NUM_BLOCKS=[4] * n, NUM_CHANNELS=w[:n], FUSE_METHOD='SUM')
             return _wrap({'MODEL': {'NAME': 'pose_hrnet', 'NUM_JOINTS': J, 'INIT_WEIGHTS': False, 'PRETRAINED': '', 'DTYPE': args.dtype,
+                                    'WEIGHT_DTYPE': weight_dtype,
                                     'EXTRA': {'FINAL_CONV_KERNEL': 1, 'PRETRAINED_LAYERS': ['*'], 'STAGE2': st(2, 1), 'STAGE3': st(3, 4),
                                               'STAGE4': st(4, 3)}}})
-        student = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256]), is_train=True).to(dev)
+        student = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256], 'fp8' if f8 else ''), is_train=True).to(dev)
         torch.manual_seed(2)
         teacher = pose_hrnet.get_pose_net(hr_cfg([48, 96, 192, 384]), is_train=False).to(dev)
         args.no_parity = args.no_cpu_baseline = True
@@ -330,7 +333,7 @@ def main():
         wall = float(t.item())
     ms_per_step = wall / args.steps * 1e3
     value = world * B * args.steps / wall
-    gfl = GFLOP_PER_IMAGE['w32<-w48@256x192' if hr else 'hg4x128<-hg8x256']
+    gfl = GFLOP_PER_IMAGE['w32<-w48@384x288' if f8 else ('w32<-w48@256x192' if hr else 'hg4x128<-hg8x256')]
     flop_step = gfl * 1e9 * B
     achieved = flop_step / (ev_ms / args.steps * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
@@ -359,12 +362,15 @@ def main():
         roofline = {'bound': 'mfma', 'achieved': step_roof['achieved'], 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': step_roof['frac'], 'traffic': None, 'note': step_roof['note']}
     out = {
-        'metric': ('images/sec FPD train step (HRNet-W32 student, HRNet-W48 teacher) 256x192' if hr else
+        'metric': ('images/sec FPD train step (HRNet-W32 student with fp8 forward convolutions, HRNet-W48 teacher) 384x288' if f8 else
+                   'images/sec FPD train step (HRNet-W32 student, HRNet-W48 teacher) 256x192' if hr else
                    'images/sec FPD train step (4-stack HG student, 8-stack teacher) 256x256'),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': ('configs[3] shapes: HRNet-W32 student + HRNet-W48 teacher, 256x192, J=17, batch %d/GPU, ' if hr else
+        'config': {'workload': ('configs[4] shapes: HRNet-W32 student (e4m3 weights + activations on v_mfma_f32_32x32x16_fp8_fp8 in the '
+                                'forward convolutions) + bf16 HRNet-W48 teacher, 384x288, J=17, batch %d/GPU, ' if f8 else
+                                'configs[3] shapes: HRNet-W32 student + HRNet-W48 teacher, 256x192, J=17, batch %d/GPU, ' if hr else
                                 'configs[1]: hourglass student S=4 F=128 + teacher S=8 F=256, 256x256, batch %d/GPU, ') % B +
                                'fused FPD step incl. Adam, teacher forward one batch ahead on a 2nd stream%s' % (' + RCCL all-reduce' if use_dist else ''),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,

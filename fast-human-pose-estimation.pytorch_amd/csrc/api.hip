@@ -15,6 +15,9 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
 int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st);
+bool fpd_conv_f8_domain(const fpd_conv_t& a);
+int fpd_conv_tile_f8_launch(const fpd_conv_t& a, const void* w8, const float* wscale, hipStream_t st);
+int fpd_weight_quant_f8_launch(const fpd_wquant_entry_t* table, int n, hipStream_t st);
 int fpd_flip_w_launch(const float* x, float* y, int64_t rows, int W, hipStream_t st);
 int fpd_flip_merge_launch(const fpd_flipmerge_t& p, hipStream_t st);
 int fpd_final_preds_launch(const fpd_finalpreds_t& p, hipStream_t st);
@@ -84,7 +87,7 @@ int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
     SZ(fpd_wprep_entry_t); SZ(fpd_bnupd_entry_t); SZ(fpd_memset_t); SZ(fpd_table_t); SZ(fpd_wreduce_entry_t); SZ(fpd_bneck_t); SZ(fpd_conv_pair_t); SZ(fpd_bneck_pair_t); SZ(fpd_ew_pair_t); SZ(fpd_pck_t); SZ(fpd_head_t); SZ(fpd_affsum_t); SZ(fpd_layout_t);
-    SZ(fpd_flipmerge_t); SZ(fpd_finalpreds_t); SZ(fpd_targets_t); SZ(fpd_warp_src_t); SZ(fpd_warp_t);
+    SZ(fpd_conv_f8_t); SZ(fpd_wquant_entry_t); SZ(fpd_flipmerge_t); SZ(fpd_finalpreds_t); SZ(fpd_targets_t); SZ(fpd_warp_src_t); SZ(fpd_warp_t);
 #undef SZ
     return -1;
 }
@@ -114,6 +117,26 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
     int rc = validate_conv(a);
     if (rc) return rc;
     rc = dispatch_conv(a, (hipStream_t)stream);
+    return rc ? rc : check_launch();
+}
+
+int fpd_conv_f8_in_domain(const fpd_conv_t* c) { return (c && fpd_conv_f8_domain(*c)) ? 1 : 0; }
+
+int fpd_conv_forward_f8(const fpd_conv_f8_t* a, fpd_stream_t stream) {
+    FPD_REQUIRE(a, "conv_f8: null pointer");
+    int rc = validate_conv(&a->c);
+    if (rc) return rc;
+    FPD_REQUIRE(a->w8 && a->w8_scale, "conv_f8: null fp8 weights / scales");
+    FPD_REQUIRE(((uintptr_t)a->w8 & 15) == 0, "conv_f8: w8 must be 16-byte aligned");
+    rc = 1;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_f8_launch(a->c, a->w8, a->w8_scale, (hipStream_t)stream);
+    if (rc == 1) rc = dispatch_conv(&a->c, (hipStream_t)stream);      // outside the fp8 domain: the bf16 weights
+    return rc ? rc : check_launch();
+}
+
+int fpd_weight_quant_f8(const fpd_wquant_entry_t* t, int32_t n, fpd_stream_t stream) {
+    FPD_REQUIRE(n == 0 || t != nullptr, "weight_quant_f8: null table");
+    int rc = fpd_weight_quant_f8_launch(t, n, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
 
@@ -362,7 +385,7 @@ int fpd_nhwc_to_nchw(const void* src, float* dst, int32_t N, int32_t C, int32_t 
 struct fpd_op {
     int32_t type;
     union {
-        fpd_affsum_t affsum; fpd_layout_t layout; fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_head_t head; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
+        fpd_affsum_t affsum; fpd_layout_t layout; fpd_conv_f8_t conv8; fpd_conv_t conv; fpd_conv_pair_t pair; fpd_bneck_t bneck; fpd_bneck_pair_t bpair; fpd_ew_pair_t epair; fpd_pck_t pck; fpd_head_t head; fpd_wgrad_t wgrad; fpd_stem_t stem; fpd_ew_t ew; fpd_loss_t loss; fpd_adam_t adam;
         fpd_memset_t mset; fpd_table_t table;
     } u;
 };
@@ -405,6 +428,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
     size_t want = 0;
     switch (op) {
         case FPD_OP_CONV: want = sizeof(fpd_conv_t); break;
+        case FPD_OP_CONV_F8: want = sizeof(fpd_conv_f8_t); break;
         case FPD_OP_WGRAD: want = sizeof(fpd_wgrad_t); break;
         case FPD_OP_CONV_PAIR: want = sizeof(fpd_conv_pair_t); break;
         case FPD_OP_BNECK_PAIR: want = sizeof(fpd_bneck_pair_t); break;
@@ -419,7 +443,7 @@ int fpd_plan_add(fpd_plan* p, int32_t op, const void* args, int64_t bytes) {
         case FPD_OP_MEMSET: case FPD_OP_NOP: want = sizeof(fpd_memset_t); break;
         case FPD_OP_AFFSUM: want = sizeof(fpd_affsum_t); break;
         case FPD_OP_NCHW2NHWC: want = sizeof(fpd_layout_t); break;
-        case FPD_OP_WPREP: case FPD_OP_BNUPD: case FPD_OP_WREDUCE: want = sizeof(fpd_table_t); break;
+        case FPD_OP_WPREP: case FPD_OP_BNUPD: case FPD_OP_WREDUCE: case FPD_OP_WQUANT: want = sizeof(fpd_table_t); break;
         default: return fpd_fail(-2, "plan_add: unknown op %d", op);
     }
     FPD_REQUIRE((size_t)bytes == want, "plan_add: op %d expects %zu bytes of args, got %lld", op, want, (long long)bytes);
@@ -458,6 +482,8 @@ int fpd_plan_wait_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
 static int run_op(const fpd_op& o, fpd_stream_t s) {
     switch (o.type) {
         case FPD_OP_CONV: return fpd_conv_forward(&o.u.conv, s);
+        case FPD_OP_CONV_F8: return fpd_conv_forward_f8(&o.u.conv8, s);
+        case FPD_OP_WQUANT: return fpd_weight_quant_f8((const fpd_wquant_entry_t*)o.u.table.table, o.u.table.n, s);
         case FPD_OP_WGRAD: return fpd_conv_wgrad(&o.u.wgrad, s);
         case FPD_OP_CONV_PAIR: return fpd_conv_forward_pair(&o.u.pair, s);
         case FPD_OP_BNECK_PAIR: return fpd_bottleneck_forward_pair(&o.u.bpair, s);

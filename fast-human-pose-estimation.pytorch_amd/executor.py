@@ -18,7 +18,8 @@ _EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd
        'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD, 'relu_mask': R.EW_RELU_MASK, 'dilate2': R.EW_DILATE2}
 _ARENA_DTYPE = {'param': torch.float32, 'grad': torch.float32, 'rstat': torch.float32, 'nbt': torch.int64,
                 'stats': torch.float64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
-                'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32, 'fold': torch.float32}
+                'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32, 'fold': torch.float32,
+                'w8': torch.uint8, 'w8s': torch.float32}
 
 
 def act_torch_dtype(dtype):
@@ -81,7 +82,7 @@ class Lowering:
         s.running_mean, s.running_var = self.A.ptr(bn.rmean), self.A.ptr(bn.rvar)
         return s
 
-    def conv(self, op):
+    def conv(self, op, plain=False):
         s = R.ConvT()
         (s.N, s.H, s.W, s.C, s.K, s.R, s.S, s.stride, s.pad, s.P, s.Q) = op.dims
         s.dtype = self.dtype
@@ -91,7 +92,23 @@ class Lowering:
         s.out_stats = p(op.out_stats)
         s.bn = self.bn(op.bn)
         s.epi_x, s.epi_bn, s.epi_stats = p(_abuf(op.epi_x)), self.bn(op.epi_bn), p(op.epi_stats)
+        if getattr(op, 'w8', None) is not None and not plain:
+            f = R.ConvF8T()
+            f.c, f.w8, f.w8_scale = s, p(op.w8), p(op.w8s)
+            return R.OP_CONV_F8, f
         return R.OP_CONV, s
+
+    def wquant(self, entries):
+        """[(master weight Buf, e4m3 Buf, scale Buf)] -> one table-driven launch (fpd_weight_quant_f8)."""
+        ents = []
+        for w, q, sc in entries:
+            e = R.WquantEntryT()
+            e.w, e.w8, e.scale = self.A.ptr(w), self.A.ptr(q), self.A.ptr(sc)
+            e.K, e.RSC = w.shape[0], w.numel // w.shape[0]
+            ents.append(e)
+        s = R.TableT()
+        s.table, s.n, s.dtype, s.max_elems = self._table(ents, R.WquantEntryT), len(ents), self.dtype, 0
+        return R.OP_WQUANT, s
 
     def bneck(self, op):
         s = R.BneckT()
@@ -232,7 +249,7 @@ class Lowering:
     def op(self, op):
         if op.kind == 'conv2':
             s = R.ConvPairT()
-            s.a, s.b = self.conv(op.a)[1], self.conv(op.b)[1]
+            s.a, s.b = self.conv(op.a, plain=True)[1], self.conv(op.b, plain=True)[1]
             return R.OP_CONV_PAIR, s
         if op.kind == 'ew2':
             s = R.EwPairT()
@@ -296,7 +313,8 @@ class GraphInstance:
         if cfg.get('arch') == 'hrnet':
             self.g = G.HRNetGraph(state.table, cfg['extra'], cfg['J'], batch, height, width, train,
                                   wlp_is_master=(self.dtype == R.F32),
-                                  wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
+                                  wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None,
+                                  fp8=bool(cfg.get('fp8', False)))
         else:
             self.g = G.HourglassGraph(state.table, cfg['F'], cfg['S'], cfg['J'], batch, height, width, train,
                                       num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
@@ -364,6 +382,11 @@ class GraphInstance:
                 entries.append((self.state.table[k], wf, wb))
         if entries:
             p.add(*self.low.wprep(entries))
+        w8 = getattr(g, 'w8', None)
+        if w8:                                     # e4m3 copies + scales of the convolutions that run on the fp8 matrix pipe
+            self.A.alloc('w8', g.w8_size)
+            self.A.alloc('w8s', g.w8s_size)
+            p.add(*self.low.wquant([(self.state.table[k], q, sc) for k, (q, sc) in w8.items()]))
         for op in g.fwd:                           # frozen fused Bottlenecks: fold BN + biases into tables once
             for sub in ((op.a, op.b) if op.kind == 'bneck2' else (op,)):
                 if sub.kind == 'bneck' and getattr(sub, 'folded', None) is not None:

@@ -72,6 +72,18 @@ class BN:
         self.count = 0                 # N*H*W of the normalised tensor
 
 
+def f8_conv_domain(dims):
+    """Shapes csrc/conv_tile_f8.hip takes (fpd_conv_f8_in_domain): stride-1 "same" 1x1 / 3x3, rows <= 128 pixels,
+    C % 32 == 0, K % 8 == 0, and a halo that fits the kernel's staging registers."""
+    n, h, w, C, K, R, S, stride, pad, P, Q = dims
+    if stride != 1 or R != S or R not in (1, 3) or pad != (R - 1) // 2 or w > 128 or w < 2:
+        return False
+    if C % 32 or K % 8 or C > 512:
+        return False
+    bk = 64 if C % 64 == 0 else 32
+    return (max(1, 128 // w) + R - 1) * w * (bk // 8) <= 2048
+
+
 class Op:
     """kind in {conv, wgrad, stem_fwd, stem_wgrad, ew, loss, adam, memset, wprep, bnupd}; free-form fields."""
 
@@ -96,6 +108,7 @@ class Op:
             return ra + rb, wa + wb
         if k == 'conv':
             rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
+            rd += [getattr(self, 'w8', None), getattr(self, 'w8s', None)]
             wr = [b(self.y), self.out_stats, self.epi_stats]
         elif k == 'head':
             rd = [b(self.y0), b(self.x), self.w_fc, self.b_fc, self.w_score, self.b_score, self.w_fc2, self.b_fc2,
@@ -357,6 +370,18 @@ class HourglassGraph:
             self.build_backward()
 
     # ---- small allocators ----
+    def _w8(self, wkey):
+        """e4m3 copy + per-output-channel scales of convolution weight `wkey` ('w8' arena: bytes, 'w8s': fp32)."""
+        tab = self.__dict__.setdefault('w8', {})
+        if wkey not in tab:
+            b = self.p[wkey]
+            q = Buf('w8', getattr(self, 'w8_size', 0), b.shape, 'w8:' + wkey)
+            self.w8_size = q.off + (b.numel + 15) // 16 * 16
+            sc = Buf('w8s', getattr(self, 'w8s_size', 0), (b.shape[0],), 'w8s:' + wkey)
+            self.w8s_size = sc.off + (b.shape[0] + 3) // 4 * 4
+            tab[wkey] = (q, sc)
+        return tab[wkey]
+
     def _wlp(self, like):
         off = self.wlp_size
         self.wlp_size += (like.numel + 7) // 8 * 8
@@ -386,6 +411,10 @@ class HourglassGraph:
                 y=y, out_stats=None, bn=bn, epi='plain', epi_x=None, epi_bn=None, epi_stats=None,
                 dims=(n, h, w, C, K, R, S, stride, pad, y.shape[1], y.shape[2]))
         y.producer = op
+        op.w8 = op.w8s = None
+        if getattr(self, 'fp8', False) and sink is None and f8_conv_domain(op.dims):
+            op.w8, op.w8s = self._w8(wkey)       # forward on the fp8 matrix pipe (csrc/conv_tile_f8.hip)
+            op.w_master = self.p[wkey]
         if bn is not None:
             self._use_bn(x, bn)
         (self.fwd if sink is None else sink).append(op)      # sink: collected by bottleneck_pair instead of issued
@@ -830,8 +859,10 @@ class HRNetGraph(HourglassGraph):
 
     MASTER_ONLY = ()
 
-    def __init__(self, params, extra, num_joints, batch, height, width, train, wlp_is_master=True, wgrad_batch=None):
+    def __init__(self, params, extra, num_joints, batch, height, width, train, wlp_is_master=True, wgrad_batch=None,
+                 fp8=False):
         self.p = params
+        self.fp8 = bool(fp8) and not wlp_is_master      # fp8 forward convolutions (bf16 storage build only)
         self.extra, self.J = extra, num_joints
         self.S = 1                                 # one heat-map
         self.N, self.H, self.W = batch, height, width

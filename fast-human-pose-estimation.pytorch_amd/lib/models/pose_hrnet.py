@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from ... import graph as G
+from ... import runtime as R
 from ._flat import BatchNorm2d, Conv2d, FlatArenaNet, ReLU
 
 logger = logging.getLogger(__name__)
@@ -124,6 +125,19 @@ class PoseHighResolutionNet(FlatArenaNet):
         J = int(cfg.MODEL.NUM_JOINTS)
         self.cfg_hg = {'arch': 'hrnet', 'extra': self.extra, 'J': J}
         self.fpd_dtype = self._dtype_from(cfg, kwargs)
+        # optional MODEL.WEIGHT_DTYPE 'fp8' (BASELINE configs[4]): forward convolutions of the bf16 build run with e4m3
+        # weights (per-output-channel scales) and e4m3 activations on the CDNA4 fp8 matrix pipe (csrc/conv_tile_f8.hip);
+        # master weights, gradients and Adam stay fp32 / bf16
+        try:
+            wd = cfg.MODEL['WEIGHT_DTYPE'] if 'WEIGHT_DTYPE' in cfg.MODEL else ''
+        except TypeError:
+            wd = getattr(cfg.MODEL, 'WEIGHT_DTYPE', '')
+        wd = str(kwargs.get('weight_dtype', wd)).lower()
+        if wd not in ('', 'none', 'bf16', 'fp32', 'fp8', 'e4m3'):
+            raise ValueError('MODEL.WEIGHT_DTYPE %r: expected fp8 or nothing' % wd)
+        self.cfg_hg['fp8'] = wd in ('fp8', 'e4m3')
+        if self.cfg_hg['fp8'] and self.fpd_dtype != R.BF16:
+            raise ValueError('MODEL.WEIGHT_DTYPE fp8 needs MODEL.DTYPE bf16 (activations are stored as bf16)')
         keys = hrnet_keys(self.extra, J)
         self._init_flat(G.ParamTable(keys, bucket_of=G.hrnet_bucket_of))
         self._build_tree()

@@ -17,7 +17,7 @@ BACKEND_MFMA, BACKEND_NAIVE, BACKEND_MFMA_GENERIC = 0, 1, 2
  EW_ADD, EW_RELU_MASK, EW_DILATE2) = range(10)
 (OP_CONV, OP_WGRAD, OP_STEM_FWD, OP_STEM_WGRAD, OP_EW, OP_LOSS, OP_ADAM, OP_MEMSET, OP_WPREP, OP_BNUPD,
  OP_WREDUCE, OP_BNECK, OP_BNECK_FOLD, OP_CONV_PAIR, OP_BNECK_PAIR, OP_EW_PAIR, OP_PCK, OP_HEAD, OP_HEAD_FOLD,
- OP_NOP, OP_AFFSUM, OP_NCHW2NHWC) = range(22)
+ OP_NOP, OP_AFFSUM, OP_NCHW2NHWC, OP_CONV_F8, OP_WQUANT) = range(24)
 AFFSUM_MAX = 4
 MAX_STACKS = 8
 MAXC = 512
@@ -35,6 +35,14 @@ class ConvT(C.Structure):
                 ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('epi', _i32),
                 ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('residual', _vp), ('y', _vp),
                 ('out_stats', _vp), ('bn', BnT), ('epi_x', _vp), ('epi_bn', BnT), ('epi_stats', _vp)]
+
+
+class ConvF8T(C.Structure):
+    _fields_ = [('c', ConvT), ('w8', _vp), ('w8_scale', _vp)]
+
+
+class WquantEntryT(C.Structure):
+    _fields_ = [('w', _vp), ('w8', _vp), ('scale', _vp), ('K', _i32), ('RSC', _i32)]
 
 
 class ConvPairT(C.Structure):
@@ -160,13 +168,16 @@ _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_st
             'fpd_loss_t': LossT, 'fpd_adam_t': AdamT, 'fpd_wprep_entry_t': WprepEntryT,
             'fpd_bnupd_entry_t': BnupdEntryT, 'fpd_memset_t': MemsetT, 'fpd_table_t': TableT,
             'fpd_wreduce_entry_t': WreduceEntryT, 'fpd_bneck_t': BneckT, 'fpd_conv_pair_t': ConvPairT, 'fpd_bneck_pair_t': BneckPairT, 'fpd_ew_pair_t': EwPairT, 'fpd_pck_t': PckT, 'fpd_head_t': HeadT, 'fpd_affsum_t': AffsumT, 'fpd_layout_t': LayoutT,
-            'fpd_flipmerge_t': FlipMergeT, 'fpd_finalpreds_t': FinalPredsT, 'fpd_targets_t': TargetsT,
+            'fpd_conv_f8_t': ConvF8T, 'fpd_wquant_entry_t': WquantEntryT, 'fpd_flipmerge_t': FlipMergeT, 'fpd_finalpreds_t': FinalPredsT, 'fpd_targets_t': TargetsT,
             'fpd_warp_src_t': WarpSrcT, 'fpd_warp_t': WarpT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'fpd_conv_forward': (C.c_int, [C.POINTER(ConvT), _vp]),
     'fpd_conv_forward_pair': (C.c_int, [C.POINTER(ConvPairT), _vp]),
+    'fpd_conv_forward_f8': (C.c_int, [C.POINTER(ConvF8T), _vp]),
+    'fpd_conv_f8_in_domain': (C.c_int, [C.POINTER(ConvT)]),
+    'fpd_weight_quant_f8': (C.c_int, [_vp, _i32, _vp]),
     'fpd_bottleneck_forward': (C.c_int, [C.POINTER(BneckT), _vp]),
     'fpd_bottleneck_fold': (C.c_int, [C.POINTER(BneckT), _vp]),
     'fpd_bottleneck_forward_pair': (C.c_int, [C.POINTER(BneckPairT), _vp]),

@@ -325,6 +325,31 @@ typedef struct {
 } fpd_pck_t;
 int fpd_pck(const fpd_pck_t* a, fpd_stream_t stream);
 
+/* ---- fp8 (OCP e4m3fn) forward convolutions on the CDNA4 fp8 matrix pipe: BASELINE configs[4] "HRNet-W32 student fp8
+ * weights (CDNA4 fp8 MFMA)" ---- */
+/* fpd_conv_forward() with e4m3 weights: `c` is the convolution exactly as fpd_conv_t describes it (c.w = the bf16
+ * working weights, used when the shape is outside the fp8 kernel's domain); w8 = the same weights as e4m3 bytes
+ * [K][R][S][C], w8_scale[k] = the fp32 scale of output channel k (w ~= w8 * scale).  The activation operand (after the
+ * fused BN+ReLU prologue) is rounded to e4m3 at unit scale, saturating at +-448, on its way into LDS; products
+ * accumulate in fp32 (v_mfma_f32_32x32x16_fp8_fp8); scale, bias, residual and the batch statistics follow in fp32.
+ * Domain of the fp8 kernel: dtype BF16, plain epilogue, stride-1 "same" 1x1/3x3, W <= 128, C % 32 == 0, K % 8 == 0. */
+typedef struct {
+    fpd_conv_t c;
+    const void* w8;
+    const float* w8_scale;
+} fpd_conv_f8_t;
+int fpd_conv_forward_f8(const fpd_conv_f8_t* a, fpd_stream_t stream);
+int fpd_conv_f8_in_domain(const fpd_conv_t* c);   /* 1 = the fp8 kernel takes this shape, 0 = falls back to c.w */
+
+/* fp32 master weights -> e4m3 + per-output-channel scale (amax / 448; 1 for an all-zero row), one launch for a table. */
+typedef struct {
+    const float* w;        /* [K][RSC] fp32 master weights (K,R,S,C order) */
+    void* w8;              /* [K][RSC] e4m3 bytes */
+    float* scale;          /* [K] */
+    int32_t K, RSC;
+} fpd_wquant_entry_t;
+int fpd_weight_quant_f8(const fpd_wquant_entry_t* table_dev, int32_t n_entries, fpd_stream_t stream);
+
 /* ---- validate / flip-test post-processing (lib/core/function.py:189-332) ---- */
 /* y[r][c] = x[r][W-1-c] for `rows` rows of W floats: the flipped input image of the flip test
  * (function.py:217-221: np.flip(input.cpu().numpy(), 3)); x is [N,3,H,W] fp32, rows = N*3*H. */
@@ -407,7 +432,8 @@ enum {
     FPD_OP_CONV = 0, FPD_OP_WGRAD = 1, FPD_OP_STEM_FWD = 2, FPD_OP_STEM_WGRAD = 3, FPD_OP_EW = 4,
     FPD_OP_LOSS = 5, FPD_OP_ADAM = 6, FPD_OP_MEMSET = 7, FPD_OP_WPREP = 8, FPD_OP_BNUPD = 9, FPD_OP_WREDUCE = 10,
     FPD_OP_BNECK = 11, FPD_OP_BNECK_FOLD = 12, FPD_OP_CONV_PAIR = 13, FPD_OP_BNECK_PAIR = 14, FPD_OP_EW_PAIR = 15, FPD_OP_PCK = 16, FPD_OP_HEAD = 17,
-    FPD_OP_HEAD_FOLD = 18, FPD_OP_NOP = 19, FPD_OP_AFFSUM = 20, FPD_OP_NCHW2NHWC = 21
+    FPD_OP_HEAD_FOLD = 18, FPD_OP_NOP = 19, FPD_OP_AFFSUM = 20, FPD_OP_NCHW2NHWC = 21, FPD_OP_CONV_F8 = 22,
+    FPD_OP_WQUANT = 23          /* args: fpd_table_t over fpd_wquant_entry_t */
 };
 typedef struct { void* ptr; int64_t bytes; } fpd_memset_t;                 /* zero-fill */
 typedef struct { const void* table; int32_t n; int32_t dtype; int64_t max_elems; } fpd_table_t;

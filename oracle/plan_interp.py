@@ -78,11 +78,26 @@ def _prologue(A, x, bn):
     return _rnd(A, y)
 
 
+def A_master(op):
+    """The fp32 master weight Buf behind a convolution's working copy (same shape, 'param' arena)."""
+    return op.w_master if getattr(op, 'w_master', None) is not None else op.w
+
+
 def run_conv(A, op):
     n, h, w, C, K, R, S, stride, pad, P, Q = op.dims
-    x = _prologue(A, _act(A, op.x), op.bn)
-    wt = A.view(op.w).float()                     # [K,R,S,C]
-    y = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if getattr(op, 'w8', None) is not None:       # fp8 forward convolution (include/fpd_amd.h fpd_conv_f8_t; oracle/fp8_ref.py):
+        from . import fp8_ref                     # prologue result rounded ONCE, to e4m3; e4m3 weights of the fp32 masters
+        x = _act(A, op.x)
+        if op.bn is not None:
+            scale, shift, _, _ = _bn_coef(A, op.bn)
+            x = torch.addcmul(shift, x, scale)
+            if op.bn.relu:
+                x = x.clamp_min(0)
+        y = fp8_ref.conv_f8(x, A.view(A_master(op)).float(), stride, pad)
+    else:
+        x = _prologue(A, _act(A, op.x), op.bn)
+        wt = A.view(op.w).float()                     # [K,R,S,C]
+        y = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), None, stride=stride, padding=pad).permute(0, 2, 3, 1)
     if op.bias is not None:
         y = y + A.view(op.bias)
     if op.residual is not None:
