@@ -224,6 +224,7 @@ def main():
                     help="hourglass = BASELINE configs[1] (the headline metric); hrnet = configs[3] shapes: HRNet-W32 student + "
                          "HRNet-W48 teacher, 256x192, J=17; hrnet_fp8 = configs[4] shapes: the same pair at 384x288 with the "
                          "student's forward convolutions on the fp8 matrix pipe (secondary lines: step-level roofline only)")
+    ap.add_argument('--no-fp8', action='store_true', help='hrnet_fp8 shapes with bf16 forward convolutions (same-shape A/B of the fp8 path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-fp32-build parity sub-object')
     ap.add_argument('--graphs', action='store_true',
@@ -273,7 +274,7 @@ def main():
                                     'WEIGHT_DTYPE': weight_dtype,
                                     'EXTRA': {'FINAL_CONV_KERNEL': 1, 'PRETRAINED_LAYERS': ['*'], 'STAGE2': st(2, 1), 'STAGE3': st(3, 4),
                                               'STAGE4': st(4, 3)}}})
-        student = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256], 'fp8' if f8 else ''), is_train=True).to(dev)
+        student = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256], 'fp8' if (f8 and not args.no_fp8) else ''), is_train=True).to(dev)
         torch.manual_seed(2)
         teacher = pose_hrnet.get_pose_net(hr_cfg([48, 96, 192, 384]), is_train=False).to(dev)
         args.no_parity = args.no_cpu_baseline = True
@@ -368,7 +369,9 @@ def main():
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': ('configs[4] shapes: HRNet-W32 student (e4m3 weights + activations on v_mfma_f32_32x32x16_fp8_fp8 in the '
+        'config': {'workload': ('configs[4] shapes with bf16 forward convolutions (A/B of the fp8 path): HRNet-W32 student + HRNet-W48 '
+                                'teacher, 384x288, J=17, batch %d/GPU, ' if (f8 and args.no_fp8) else
+                                'configs[4] shapes: HRNet-W32 student (e4m3 weights + activations on v_mfma_f32_32x32x16_fp8_fp8 in the '
                                 'forward convolutions) + bf16 HRNet-W48 teacher, 384x288, J=17, batch %d/GPU, ' if f8 else
                                 'configs[3] shapes: HRNet-W32 student + HRNet-W48 teacher, 256x192, J=17, batch %d/GPU, ' if hr else
                                 'configs[1]: hourglass student S=4 F=128 + teacher S=8 F=256, 256x256, batch %d/GPU, ') % B +
