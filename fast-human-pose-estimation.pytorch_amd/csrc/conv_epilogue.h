@@ -112,6 +112,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     const T* ex = reinterpret_cast<const T*>(a.epi_x);
     const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
     const bool want_stats = (a.out_stats != nullptr) || bwd;
+    const int edbg = a._pad;                               // FPD_EPI_DBG ablation bits (timing experiments only; 0 in production)
     float bias[VEC], esc[VEC], esh[VEC], emu[VEC], eis[VEC];
     float f1[VEC], f2[VEC], cshift[VEC];
     int nrow = 0;
@@ -212,12 +213,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                         }
                         ++nrow;
                     }
-                    *reinterpret_cast<uint4*>(y + off) = packed;
+                    if (!(edbg & 4)) *reinterpret_cast<uint4*>(y + off) = packed;
                 }
             }
         }
     }
-    if (want_stats) {
+    if (want_stats && !(edbg & 1)) {
         double s1[VEC], s2[VEC];
         if constexpr (sizeof(T) == 2) {
             // bf16 build: the lanes of a wave that own the same channel vector are combined in fp32 first (shuffles of
@@ -286,8 +287,10 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 double u1 = 0.0, u2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { u1 += s_red[(w * BNT + t) * 2]; u2 += s_red[(w * BNT + t) * 2 + 1]; }
-                atomicAdd(st + k, u1);
-                atomicAdd(st + K + k, u2);
+                if (!(edbg & 2)) {
+                    atomicAdd(st + k, u1);
+                    atomicAdd(st + K + k, u2);
+                }
             }
         }
     }

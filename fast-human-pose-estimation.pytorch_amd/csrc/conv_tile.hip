@@ -286,11 +286,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     }
 }
 
-// MINB = resident blocks per CU the register allocation aims at: 2 (<= 256 VGPRs, the default) or 4 (<= 128 VGPRs; the
-// FPD_CONV_OCC experiment: BK = 32 chunks and TN <= 2 keep a block under 40 KB of LDS, so four blocks overlap their load /
-// MFMA / store phases on one CU instead of two)
-template <typename T, int TN, int BK, bool ALLW, int MINB = 2>
-__global__ __launch_bounds__(256, MINB) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo, const int dbg) {
+template <typename T, int TN, int BK, bool ALLW>
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo, const int dbg) {
     conv_tile_body<T, TN, BK, ALLW>(a, geo, dbg, blockIdx.x, blockIdx.y);
 }
 
@@ -337,28 +334,24 @@ static size_t tile_lds(const fpd_conv_t& c) {
     return (size_t)(hrows * WP + 3) * LD * sizeof(T) + (size_t)(ALLW ? 9 : 2) * 32 * TN * LD * sizeof(T);
 }
 
-// FPD_CONV_OCC=n (default 0 = off): bf16 convolutions whose grid has at least n blocks run the 4-blocks-per-CU variant
-static int occ_min_blocks() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_OCC"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
-template <typename T, int TN, int BK, bool ALLW, int MINB = 2>
+template <typename T, int TN, int BK, bool ALLW>
 int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
     if (lds > LDS_MAX) return 1;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW, MINB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
     dim3 grid(tiles_of(a), cdiv(a.K, 32 * TN));
     static const int dbg = getenv("FPD_CONV_DBG") ? atoi(getenv("FPD_CONV_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW, MINB>), grid, dim3(256), lds, st, a, make_geo<T, BK>(a), dbg);
+    static const int edbg = getenv("FPD_EPI_DBG") ? atoi(getenv("FPD_EPI_DBG")) : 0;    // epilogue ablation bits, travel in a._pad
+    fpd_conv_t ac = a;
+    ac._pad = edbg;
+    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, ac, make_geo<T, BK>(a), dbg);
     return 0;
 }
 template <typename T, int TN, int BK>
@@ -377,13 +370,6 @@ int launch_tile_tn(const fpd_conv_t& a, hipStream_t st) {
     const int mt = tiles_of(a);
     int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
     while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;     // small layers: more, shorter blocks
-    if constexpr (BK == 32 && sizeof(T) == 2) {
-        const int occ = occ_min_blocks();
-        if (occ > 0 && mt * cdiv(a.K, 64) >= occ) {               // large grids: 4 resident blocks per CU (TN <= 2)
-            if (tn >= 2) return launch_tile_v<T, 2, BK, false, 4>(a, st);
-            return launch_tile_v<T, 1, BK, false, 4>(a, st);
-        }
-    }
     if (tn == 4) return launch_tile<T, 4, BK>(a, st);
     if (tn == 2) return launch_tile<T, 2, BK>(a, st);
     return launch_tile<T, 1, BK>(a, st);
@@ -464,8 +450,7 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st) {
     if (!tile_domain(a)) return 1;
     if (a.dtype == FPD_BF16) {
-        int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
-        if (bk == 64 && occ_min_blocks() > 0 && tiles_of(a) * cdiv(a.K, 64) >= occ_min_blocks()) bk = 32;   // FPD_CONV_OCC experiment
+        const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
         if (!halo_fits(a, bk / 8)) return 1;
         if (bk == 64) return launch_tile_tn<bf16_t, 64>(a, st);
         if (bk == 32) return launch_tile_tn<bf16_t, 32>(a, st);

@@ -12,11 +12,13 @@ Design (MI355X-first): every BatchNorm+ReLU is folded into the *c
 operand load; every producer accumulates the batch statistics the next BN needs in its epilogue;
 activations are NHWC; tensors are placed in one arena by liveness over the whole fwd+bwd list.
 """
+import os
 from collections import OrderedDict
 
 BN_EPS = 1e-5        # torch default, hourglass.py:18
 BN_MOMENTUM = 0.1    # hourglass.py:10
-STATS_REPLICAS = 4   # include/fpd_amd.h FPD_STATS_REPLICAS: statistics buffers are [R][2][C]
+STATS_REPLICAS = int(os.environ.get('FPD_STATS_REPLICAS', '4'))   # include/fpd_amd.h FPD_STATS_REPLICAS: statistics buffers are
+# [R][2][C]; the environment override exists for same-box A/B runs against a library built with -DFPD_STATS_REPLICAS=n
 # Multi-lane execution (see schedule.py).  Measured on MI355X/ROCm 7.2: a same-stream kernel->kernel dependency costs
 # ~0.9 us, a cross-stream one (event record + wait) ~10 us, so lanes are coarse: only hourglass up-branches of the
 # LANE_LEVELS largest resolutions get a lane, and weight gradients are issued in batches of WGRAD_BATCH on one lane.

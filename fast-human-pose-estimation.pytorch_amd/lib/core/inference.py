@@ -28,7 +28,8 @@ def final_preds_device(batch_heatmaps, trans, post_process):
     a.N, a.J, a.H, a.W, a.post_process = n, j, h, w, int(bool(post_process))
     a.hm, a.coords, a.maxvals = hm.data_ptr(), coords.data_ptr(), maxvals.data_ptr()
     if trans is not None:
-        assert trans.dtype == torch.float64 and tuple(trans.shape) == (n, 2, 3) and trans.is_cuda and trans.is_contiguous()
+        assert trans.dtype == torch.float64 and tuple(trans.shape) == (n, 2, 3) and trans.is_cuda
+        trans = trans.contiguous()
         a.trans, a.preds = trans.data_ptr(), preds.data_ptr()
     R.check(R.lib().fpd_final_preds(a, R.current_stream()), 'fpd_final_preds')
     return coords, preds, maxvals

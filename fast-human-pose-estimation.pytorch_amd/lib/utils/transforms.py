@@ -72,7 +72,7 @@ def _third_point(a, b):
 def _three_point_affine(src, dst):
     """The 2x3 matrix taking src[i] to dst[i], i < 3 (what cv2.getAffineTransform computes), float64."""
     lhs = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], axis=1)
-    return np.linalg.solve(lhs, np.asarray(dst, np.float64)).T
+    return np.ascontiguousarray(np.linalg.solve(lhs, np.asarray(dst, np.float64)).T)
 
 
 def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):

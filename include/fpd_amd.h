@@ -31,7 +31,9 @@ enum { FPD_F32 = 0, FPD_BF16 = 1 };
 /* Every per-channel statistics buffer (BN forward {sum, sumsq}; BN backward {sum dz, sum dz*xhat}) holds
  * FPD_STATS_REPLICAS independent partial copies: layout [R][2][C] fp64.  Producer block b adds into replica b % R
  * (thousands of blocks adding into ONE address serialise at ~12 ns per atomic); consumers sum the replicas. */
+#ifndef FPD_STATS_REPLICAS
 #define FPD_STATS_REPLICAS 4
+#endif
 enum { FPD_BN_NONE = 0, FPD_BN_TRAIN = 1, FPD_BN_EVAL = 2 };
 enum { FPD_EPI_PLAIN = 0, FPD_EPI_BNRELU_BWD = 1 };
 enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1, FPD_BACKEND_MFMA_GENERIC = 2 };

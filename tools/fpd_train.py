@@ -109,7 +109,7 @@ def main():
     train_set = SyntheticPose(cfg, cfg.DATASET.NUM_SAMPLES, seed=rank)
     loader = torch.utils.data.DataLoader(train_set, batch_size=bs, shuffle=cfg.TRAIN.SHUFFLE, num_workers=0,
                                          pin_memory=cfg.PIN_MEMORY, drop_last=True, collate_fn=train_set.collate)
-    valid_set = SyntheticPose(cfg, cfg.DATASET.NUM_VALID_SAMPLES, seed=10007)
+    valid_set = SyntheticPose(cfg, cfg.DATASET.NUM_VALID_SAMPLES, seed=1009)
     valid_loader = torch.utils.data.DataLoader(valid_set, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU, shuffle=False, num_workers=0,
                                                pin_memory=cfg.PIN_MEMORY, collate_fn=valid_set.collate)
     if args.max_iters:
