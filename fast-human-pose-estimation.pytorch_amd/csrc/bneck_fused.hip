@@ -96,6 +96,11 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef FPD_BNECK_TIMING
     long long stamps[8];
+    long long astamp[10];                        // phase A: [0] before the first staging, then after every chunk step
+    int acnt = 0;
+#define ASTAMP() do { if (tid == 0 && bid_in == 0 && acnt < 10) astamp[acnt++] = clock64(); } while (0)
+#else
+#define ASTAMP() do { } while (0)
 #endif
     STAMP(0);
     const int q = wave & 3, hC = wave >> 2;     // pixel group (32 px) and channel half of this wave
@@ -162,27 +167,31 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             rw[kc][i] = *reinterpret_cast<const u32x4*>(w1 + (w1o[i] + kc * 64));
         });
     };
-    auto a_store = [&](auto kcc) __attribute__((always_inline)) {
-        constexpr int kc = decltype(kcc)::value;
+    // staging of chunk kc in NSL = 2 + W1V slices (x vector 0, x vector 1, then the w1 vectors): the chunk loop places one
+    // slice behind the MFMAs of each k-step, so that the VALU / LDS-store work of the next chunk runs while the matrix
+    // pipe executes (a wave issues in order: staged as one block it would only start once all MFMAs of the step are issued)
+    constexpr int NSL = 2 + W1V;
+    auto a_store_slice = [&](auto kcc, auto slc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value, sl = decltype(slc)::value;
         bf16_t* dst = sR2 + (kc & 1) * ASTG;
-        f32x4 sc[2], sh[2];
-        sc[0] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv);
-        sc[1] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv + 4);
-        sh[0] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv);
-        sh[1] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv + 4);
-        static_for<2>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+        if constexpr (sl < 2) {
+            f32x4 sc[2], sh[2];
+            sc[0] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv);
+            sc[1] = *reinterpret_cast<const f32x4*>(s_sc1 + kc * 64 + xcv + 4);
+            sh[0] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv);
+            sh[1] = *reinterpret_cast<const f32x4*>(s_sh1 + kc * 64 + xcv + 4);
             float f[8];
-            const u32x4 r = rx[kc][i];
+            const u32x4 r = rx[kc][sl];
             DT<bf16_t>::unpack(make_uint4(r[0], r[1], r[2], r[3]), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), 0.f);
-            *reinterpret_cast<uint4*>(dst + xl + 64 * i * LDX) = DT<bf16_t>::pack(f);
-        });
-        static_for<W1V>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            *reinterpret_cast<u32x4*>(dst + w1l[i]) = rw[kc][i];
-        });
+            *reinterpret_cast<uint4*>(dst + xl + 64 * sl * LDX) = DT<bf16_t>::pack(f);
+        } else if constexpr (sl < NSL) {
+            *reinterpret_cast<u32x4*>(dst + w1l[sl - 2]) = rw[kc][sl - 2];
+        }
+    };
+    auto a_store = [&](auto kcc) __attribute__((always_inline)) {
+        static_for<NSL>([&](auto slc) { a_store_slice(kcc, slc); });
     };
     // ---- weight-tile pipeline of phases B/C: two register sets, tile t travels in set t & 1 and is requested two
     //      steps before the step that multiplies with it ----
@@ -292,9 +301,14 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         if (pp + 1 < npass) a_load(kcc);                                       // xo/xok already describe pass pp+1
         else if constexpr (kc < 2) t_load(kcc);
     };
+#ifdef FPD_BNECK_TIMING
+    acnt = 0;
+#endif
+    ASTAMP();
     a_store(std::integral_constant<int, 0>{});
     refill(std::integral_constant<int, 0>{}, 0);
     __syncthreads();
+    ASTAMP();
     for (int p = 0; p < npass; ++p) {
         f32x16 acc[TNH];
 #pragma unroll
@@ -303,28 +317,36 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
         static_for<NCH>([&](auto kcc) {
             constexpr int kc = decltype(kcc)::value;
-            if constexpr (kc + 1 < NCH) {
-                a_store(std::integral_constant<int, (kc + 1) % NCH>{});
-                refill(std::integral_constant<int, (kc + 1) % NCH>{}, p);
-            } else {
-                if (p + 1 < npass) {
-                    a_store(std::integral_constant<int, 0>{});
-                    if (p + 2 < npass) pass_addr(p + 2);                       // (never taken: npass <= 2)
-                    refill(std::integral_constant<int, 0>{}, p + 1);
+            // slice sl of the staging of the NEXT chunk (next pass's chunk 0 behind the last chunk) + the refill of its slot
+            auto stage_slice = [&](auto slc) __attribute__((always_inline)) {
+                constexpr int sl = decltype(slc)::value;
+                if constexpr (kc + 1 < NCH) {
+                    a_store_slice(std::integral_constant<int, (kc + 1) % NCH>{}, slc);
+                    if constexpr (sl == NSL - 1) refill(std::integral_constant<int, (kc + 1) % NCH>{}, p);
+                } else {
+                    if (p + 1 < npass) {
+                        a_store_slice(std::integral_constant<int, 0>{}, slc);
+                        if constexpr (sl == NSL - 1) {
+                            if (p + 2 < npass) pass_addr(p + 2);               // (never taken: npass <= 2)
+                            refill(std::integral_constant<int, 0>{}, p + 1);
+                        }
+                    }
                 }
-            }
+            };
             const bf16_t* xrow = sR2 + (kc & 1) * ASTG + (q * 32 + (lane & 31)) * LDX + koff;
             const bf16_t* wrow = sR2 + (kc & 1) * ASTG + 128 * LDX + (hC * CW + (lane & 31)) * LDX + koff;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            static_for<4>([&](auto kkc) {
+                constexpr int kk = decltype(kkc)::value;
                 const bf16x8 px = *reinterpret_cast<const bf16x8*>(xrow + kk * 16);
 #pragma unroll
                 for (int tn = 0; tn < TNH; ++tn) {
                     const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + tn * 32 * LDX + kk * 16);
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, px, acc[tn], 0, 0, 0);
                 }
-            }
+                stage_slice(kkc);                                              // NSL <= 4 slices, one per k-step
+            });
             __syncthreads();
+            ASTAMP();
         });
         if (p + 1 == npass) {                    // both staging buffers are dead: the first two weight tiles of phase B
             t_dma(std::integral_constant<int, 0>{});     // travel while the a2 image is written out
@@ -497,6 +519,10 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         printf("bneck W=%d: setup %lld | phaseA %lld | tile0 %lld | B(9 taps) %lld | a3+C %lld | epilogue %lld | total %lld cycles\n",
                W, stamps[1] - stamps[0], stamps[2] - stamps[1], stamps[3] - stamps[2], stamps[4] - stamps[3],
                stamps[5] - stamps[4], stamps[6] - stamps[5], stamps[6] - stamps[0]);
+    if (tid == 0 && bid_in == 0 && acnt == 10)
+        printf("  phase A steps: first-stage %lld | pass0 %lld %lld %lld %lld | pass1 %lld %lld %lld %lld | a2 write %lld\n",
+               astamp[1] - astamp[0], astamp[2] - astamp[1], astamp[3] - astamp[2], astamp[4] - astamp[3], astamp[5] - astamp[4],
+               astamp[6] - astamp[5], astamp[7] - astamp[6], astamp[8] - astamp[7], astamp[9] - astamp[8], stamps[2] - astamp[9]);
 #endif
 }
 
