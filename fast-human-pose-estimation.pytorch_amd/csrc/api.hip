@@ -15,6 +15,7 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
 int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st);
+int fpd_conv_smallc_launch(const fpd_conv_t& a, hipStream_t st);
 bool fpd_conv_f8_domain(const fpd_conv_t& a);
 int fpd_conv_tile_f8_launch(const fpd_conv_t& a, const void* w8, const float* wscale, hipStream_t st);
 int fpd_weight_quant_f8_launch(const fpd_wquant_entry_t* table, int n, hipStream_t st);
@@ -109,6 +110,7 @@ static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     int rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
+    if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_smallc_launch(*a, st);   // tiny input-channel counts (3, 17)
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
     return rc;
 }

@@ -141,6 +141,9 @@ CONV_CASES = [
     (1, 64, 64, 64, 64, 3, 1, 'train', True, True),     # cfg-1 student 3x3 @64^2
     (2, 8, 8, 256, 128, 1, 0, 'eval', False, False),    # teacher 1x1 256->128
     (2, 8, 8, 48, 96, 3, 1, 'train', False, True),      # HRNet-W48 widths (not multiples of 32/64)
+    (2, 16, 16, 3, 64, 3, 1, None, False, True),        # conv_smallc: HRNet's first stem conv (C = 3), statistics for bn1
+    (2, 16, 12, 17, 32, 1, 0, None, False, False),      # conv_smallc: data gradient of the J = 17 final layer
+    (1, 9, 7, 5, 8, 1, 0, None, True, False),           # conv_smallc: J = 5 test networks, ragged M, accumulate source
 ]
 
 
