@@ -87,13 +87,14 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
                 for (int j = 0; j < VEC; ++j) o[j] = bn_act(v[j], s_t0[cv + j], s_t1[cv + j], a.bn.relu);
                 stv<T>(y + (size_t)pix * C + cv, o);
             } else if (OP == FPD_EW_BNRELU_BWD_R) {
-                float v[VEC], g[VEC];
+                float v[VEC], g[VEC], mk[VEC];
                 ldv<T>(x + (size_t)pix * C + cv, v);
                 ldv<T>(dy + (size_t)pix * C + cv, g);
+                if (x2 != nullptr) ldv<T>(x2 + (size_t)pix * C + cv, mk);     // mask source: forward output of a relu(sum) op
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float z = fmaf(v[j], s_t0[cv + j], s_t1[cv + j]);
-                    o[j] = (!a.bn.relu || z > 0.f) ? g[j] : 0.f;
+                    const float z = x2 != nullptr ? mk[j] : fmaf(v[j], s_t0[cv + j], s_t1[cv + j]);
+                    o[j] = ((x2 == nullptr && !a.bn.relu) || z > 0.f) ? g[j] : 0.f;
                     const double r = (double)DT<T>::rnd(o[j]);
                     acc1[j] += r;
                     acc2[j] += r * (double)((v[j] - s_t2[cv + j]) * s_t3[cv + j]);

@@ -787,10 +787,14 @@ class HourglassGraph:
             self.bwd.append(o)
             return o
         g = dy
+        fused = None        # a full-resolution train-BN term takes the ReLU mask into its statistics pass (one launch for both)
         if op.relu:
             g = Act(op.y.shape, 'g:' + op.y.name)
-            ew('relu_mask', op.y.shape, x=op.y, dy=dy, y=g)
-        for t, bn, up in op.terms:
+            if os.environ.get('FPD_FUSE_MASK', '1') != '0':
+                fused = next((t for t, bn, up in op.terms if up == 1 and bn is not None and bn.mode == 'train' and t.needs_grad), None)
+            if fused is None:
+                ew('relu_mask', op.y.shape, x=op.y, dy=dy, y=g)
+        for t, bn, up in sorted(op.terms, key=lambda tm: tm[0] is not fused):      # the producer of g first
             if not t.needs_grad:
                 continue
             gj = g
@@ -805,7 +809,10 @@ class HourglassGraph:
             if bn.mode != 'train':
                 raise AssertionError('backward through an eval-mode BN term')
             bstats = self._stats(bn.C, 'bstats:' + bn.name)
-            ew('bnrelu_bwd_r', t.shape, x=t, dy=gj, y=None, bstats=bstats, bn=bn)          # statistics only (y = None)
+            if t is fused:     # g = dy * (y > 0) written AND its two BN-backward sums, in one pass
+                ew('bnrelu_bwd_r', t.shape, x=t, x2=op.y, dy=dy, y=g, bstats=bstats, bn=bn)
+            else:
+                ew('bnrelu_bwd_r', t.shape, x=t, dy=gj, y=None, bstats=bstats, bn=bn)      # statistics only (y = None)
             add, out = self._contribute(t)
             ew('bn_bwd_apply', t.shape, x=t, dy=gj, add=add, y=out, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
                dbeta=self.p.grad(bn.name + '.bias'), bn=bn)

@@ -170,7 +170,8 @@ typedef struct {
 
 /* Elementwise / pooling ops on NHWC tensors.  `op` selects the function:
  *  BNRELU_FWD   y = relu(bn(x)); out_stats += stats(y)                  (hourglass.py:173-174)
- *  BNRELU_BWD_R dz = dy * (yfwd > 0) -> y ; bstats += {sum dz, sum dz*xhat(x)}
+ *  BNRELU_BWD_R dz = dy * (yfwd > 0) -> y ; bstats += {sum dz, sum dz*xhat(x)}   (yfwd = relu(bn(x)), or x2 when given: the
+ *               forward output of an HRNet block tail relu(bn(conv) + skip), pose_hrnet.py:52-57 -- mask and sums in one pass)
  *  BN_BWD_APPLY y = add + gamma*invstd*(dz - s1/n - xhat(x)*s2/n)       (BatchNorm backward; dz in `dy`)
  *  MAXPOOL_FWD  y = maxpool2x2(x); out_stats += stats(y)               (hourglass.py:82,177)
  *  MAXPOOL_BWD  y = add + (x is the first max of its window ? dy : 0)

@@ -198,7 +198,10 @@ def run_ew(A, op):
         x, dy = _act(A, op.x), _act(A, op.dy)
         scale, shift, mean, invstd = _bn_coef(A, op.bn)
         z = torch.addcmul(shift, x, scale)
-        dz = torch.where(z > 0, dy, torch.zeros_like(dy)) if op.bn.relu else dy
+        if getattr(op, 'x2', None) is not None:   # mask source = the forward OUTPUT of an affsum op (relu of a sum), not bn(x)
+            dz = torch.where(_act(A, op.x2) > 0, dy, torch.zeros_like(dy))
+        else:
+            dz = torch.where(z > 0, dy, torch.zeros_like(dy)) if op.bn.relu else dy
         dzr = _rnd(A, dz).double()
         st = A.view(op.bstats)[0]
         st[0] += dzr.sum((0, 1, 2))

@@ -54,16 +54,26 @@ def test_affsum_relu_mask_dilate_and_stats_only_sums(case, dtype):
     g = bt.act((N, H, W, C), None, 'g')
     dil = bt.act((N, 2 * H, 2 * W, C), None, 'dil')
     bst = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
+    # block-tail backward in one pass: g = dy * (mask source > 0) written AND the BN-backward sums of term x1 (x2 = mask source)
+    mk = bt.act((N, H // 2, W // 2, C), rnd(gen, N, H // 2, W // 2, C), 'mk')
+    dy2 = bt.act((N, H // 2, W // 2, C), rnd(gen, N, H // 2, W // 2, C), 'dy2')
+    g2 = bt.act((N, H // 2, W // 2, C), None, 'g2')
+    bst2 = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
     ops = [G.Op('affsum', terms=[(x0, None, 1), (x1, bn1, 2), (x2, bn2, 4), (x3, bn3, 1)], y=y, relu=True, out_stats=None,
                 dims=(N, H, W, C), extra_in=[x0, x1, x2, x3]),
            ew('relu_mask', (N, H, W, C), x=y, dy=dy, y=g),
            ew('dilate2', (N, 2 * H, 2 * W, C), x=g, y=dil),
-           ew('bnrelu_bwd_r', (N, H // 2, W // 2, C), x=x1, dy=x1, y=None, bstats=bst, bn=bn1)]
+           ew('bnrelu_bwd_r', (N, H // 2, W // 2, C), x=x1, dy=x1, y=None, bstats=bst, bn=bn1),
+           ew('bnrelu_bwd_r', (N, H // 2, W // 2, C), x=x1, x2=mk, dy=dy2, y=g2, bstats=bst2, bn=bn1)]
     bt.realise().run(ops, 0)
     bt.compare(y, label='affsum %s' % (case,), **TOL[dtype])
     bt.compare(g, label='relu_mask', **TOL[dtype])
     bt.compare(dil, label='dilate2', **TOL[dtype])
     bt.compare(bst, atol=TOL[dtype]['atol'] * bn1.count, rtol=TOL[dtype]['rtol'], label='bn sums (no store)')
+    bt.compare(g2, label='masked gradient (mask source x2)', **TOL[dtype])
+    bt.compare(bst2, atol=TOL[dtype]['atol'] * bn1.count, rtol=TOL[dtype]['rtol'], label='bn sums of the masked gradient')
+    exp = torch.where(bt.cpu.view(mk.buf).float() > 0, bt.cpu.view(dy2.buf).float(), torch.zeros(1))
+    assert torch.equal(bt.gpu.view(g2.buf).float().cpu(), exp.to(bt.cpu.view(g2.buf).dtype).float())      # a mask is exact
 
 
 S2 = [(2, 16, 12, 32, 64), (2, 32, 24, 16, 16), (1, 64, 48, 64, 128), (3, 8, 6, 8, 8), (2, 64, 64, 3, 64)]
