@@ -24,7 +24,7 @@ STATS_REPLICAS = int(os.environ.get('FPD_STATS_REPLICAS', '4'))   # include/fpd_
 # LANE_LEVELS largest resolutions get a lane, and weight gradients are issued in batches of WGRAD_BATCH on one lane.
 WGRAD_LANES = 1
 LANE_LEVELS = 0
-WGRAD_BATCH = 24
+WGRAD_BATCH = 8     # re-swept in round 2 on one box: 1/2/4/8/12/16/24/32 -> 11.92/11.83/11.69/11.67/11.81/11.83/11.90/11.99 ms (the lane tail before Adam)
 
 
 class Buf:
