@@ -355,7 +355,9 @@ def main():
                     'frac': round(k_ach / peak, 4), 'traffic': traffic, 'kernel': dom['name'],
                     'avg_us': round(dom['us'], 2), 'flop_per_launch': dom['flops'],
                     'algorithmic_bytes_per_launch': dom['bytes_algorithmic'],
-                    'note': 'dominant (kernel, shape) of the step: 17 launches/step; %d back-to-back launches timed with HIP '
+                    'note': 'dominant (kernel, shape) of the step: 17 launches/step, timed AS LAUNCHED IN THE STEP (persistent grid capped at '
+                            'FPD_BNECK_BLOCKS=128 of 256 CUs so that the concurrent student chain finds free compute units; uncapped the '
+                            'same kernel runs ~100 us = 0.22 of peak, DESIGN.md section 5); %d back-to-back launches timed with HIP '
                             'events on the launch stream after the timed region; traffic = HBM bytes/launch from the committed '
                             'rocprofv3 --pmc passes (profiles/), null if absent' % dom['launches'],
                     'step': step_roof}

@@ -553,7 +553,8 @@ static int bneck_block_cap() {
     static int cap = 0;
     if (!cap) {
         const char* e = getenv("FPD_BNECK_BLOCKS");
-        cap = e ? atoi(e) : 160;       // measured (r01, pipelined step): 1024/256/224/192/160/128 -> 13.56/13.86/13.37/13.30/13.21/13.23 ms
+        cap = e ? atoi(e) : 128;       // measured (r01, pipelined step): 1024/256/224/192/160/128 -> 13.56/13.86/13.37/13.30/13.21/13.23 ms;
+                                       // r02 (wgrad batches of 8, same box): 96/112/128/144/160 -> 11.71/11.69/11.51/11.68/11.67 ms
         if (cap < 8) cap = 8;
     }
     return cap;
