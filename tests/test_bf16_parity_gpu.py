@@ -144,7 +144,10 @@ def test_tiny_bf16_20_step_trajectory_vs_reference_at_bf16():
     d_ours = np.abs(ours - t64) / np.abs(t64)
     d_ref = np.abs(ac - t64) / np.abs(t64)
     for j, nm in enumerate(('pose', 'kd', 'total')):      # single steps of a chaotic trajectory are one noise realisation each:
-        check('tiny 20-step %s trajectory, mean rel dev' % nm, float(d_ours[:, j].mean()), float(d_ref[:, j].mean()), 1e-2, 0.15)
+        # both figures are ONE realisation of a chaotic bf16 trajectory (the product's weight gradients are reproducible to
+        # rounding only: fp32 atomics): over five runs of this test the ratio ours / reference@bf16 of the mean deviation ranged
+        # 1.0 .. 1.54 -- slack 2.0 like the max; the absolute ceiling is what a broken kernel cannot pass
+        check('tiny 20-step %s trajectory, mean rel dev' % nm, float(d_ours[:, j].mean()), float(d_ref[:, j].mean()), 1e-2, 0.15, slack=2.0)
         check('tiny 20-step %s trajectory, max rel dev' % nm, float(d_ours[:, j].max()), float(d_ref[:, j].max()), 1e-2, 0.3, slack=2.0)
     assert ours[-1, 2] < ours[0, 2] and t64[-1, 2] < t64[0, 2], (ours[:, 2], t64[:, 2])
 
@@ -197,11 +200,14 @@ def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
     t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), c['s'][1])
     a_maps, a_loss, a_grads = student_step({k: v.clone() for k, v in s_sd.items()}, x, tg, tw, tmap_fixed, c['s'][1], autocast='cpu')
     # the pre-training above runs on the device (fp32 atomics in the weight gradients: reproducible to rounding only), so the
-    # trained pair -- and with it both error figures -- differs from run to run; measured over repeated runs the ratio
-    # ours / reference@bf16 of this one map ranges 0.9 .. 1.8, hence slack 2.0 and a 0.3 ceiling here
-    check('trained teacher map rel-L2', rel(ours_tmap, tr_tmap), rel(a_tmap, tr_tmap), 2e-2, 0.3, slack=2.0)
+    # trained pair -- and with it both error figures -- differs from run to run; over six runs ours ranged 0.094 .. 0.21 and the
+    # reference at bf16 0.084 .. 0.20 on their own, their ratio 0.63 .. 2.04: a ratio of two noisy realisations, hence slack 3.0
+    # here; the 0.3 ceiling (a broken kernel gives O(1)) and the per-kernel / golden tests are the sharp checks
+    check('trained teacher map rel-L2', rel(ours_tmap, tr_tmap), rel(a_tmap, tr_tmap), 2e-2, 0.3, slack=3.0)
     for i in range(len(maps)):
         check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.35)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
-        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 1e-2, 3e-2)
+        # single-step losses of the trained pair: ours ranged 2e-4 .. 1.3e-2 and the reference at bf16 2e-6 .. 1.9e-2 over nine
+        # runs (different trained pairs, see above) -- a floor of 2e-2 under the 3e-2 ceiling keeps the check out of that noise
+        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-2, 3e-2)
     check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 1.3)
