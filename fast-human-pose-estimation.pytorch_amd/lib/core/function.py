@@ -172,7 +172,8 @@ def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, 
 
 
 def _to_numpy(v):
-    return v.numpy() if torch.is_tensor(v) else __import__('numpy').asarray(v)
+    import numpy as np
+    return v.numpy() if torch.is_tensor(v) else np.asarray(v)
 
 
 def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, writer_dict=None):
