@@ -61,3 +61,48 @@ def test_missing_library_is_an_error_not_a_fallback(runtime, monkeypatch):
     monkeypatch.setattr(runtime, 'LIB_PATH', '/nonexistent/libfpd_amd.so')
     with pytest.raises(runtime.FpdError):
         runtime.lib()
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_device(runtime):
+    """validate / data-pipeline / fp8 entry points: bad arguments are refused before anything is launched."""
+    R, lib = runtime, runtime.lib()
+    err = lambda: lib.fpd_last_error().decode()
+    assert lib.fpd_flip_w(None, None, 4, 4, None) != 0 and 'null' in err()
+    m = R.FlipMergeT()
+    assert lib.fpd_flip_merge(m, None) != 0 and 'null' in err()
+    m.a, m.b, m.y = 8, 16, 24
+    m.N, m.J, m.H, m.W = 1, 40, 4, 4
+    assert lib.fpd_flip_merge(m, None) != 0 and 'J <=' in err()
+    m.J = 4
+    m.src[2] = 9
+    assert lib.fpd_flip_merge(m, None) != 0 and 'out of range' in err()
+    m.src[2] = 2
+    m.y = m.b                                     # in-place over the flipped map would read what it overwrites
+    assert lib.fpd_flip_merge(m, None) != 0 and 'aliased' in err()
+    f = R.FinalPredsT()
+    f.N, f.J, f.H, f.W = 1, 2, 4, 4
+    f.hm, f.coords, f.maxvals, f.trans = 8, 16, 24, 32      # trans without preds
+    assert lib.fpd_final_preds(f, None) != 0 and 'go together' in err()
+    t = R.TargetsT()
+    t.B, t.J, t.H, t.W, t.patch = 1, 2, 8, 8, 12             # even patch edge
+    t.joints, t.vis, t.g, t.target, t.weight = 8, 16, 24, 32, 40
+    t.stride_x = t.stride_y = 4.0
+    assert lib.fpd_render_targets(t, None) != 0 and 'bad dims' in err()
+    w = R.WarpT()
+    w.B, w.H, w.W, w.src, w.out = 1, 8, 8, 8, 16
+    assert lib.fpd_warp_affine(w, None) != 0 and 'std' in err()
+    c8 = R.ConvF8T()
+    c = c8.c
+    c.x = c.w = c.y = 8
+    c.N, c.H, c.W, c.C, c.K, c.R, c.S, c.stride, c.pad, c.P, c.Q, c.dtype = 1, 8, 8, 32, 32, 3, 3, 1, 1, 8, 8, R.BF16
+    assert lib.fpd_conv_forward_f8(c8, None) != 0 and 'null fp8' in err()
+    c8.w8, c8.w8_scale = 24, 32                               # e4m3 weights must be 16-byte aligned
+    assert lib.fpd_conv_forward_f8(c8, None) != 0 and 'aligned' in err()
+    assert lib.fpd_conv_f8_in_domain(c) == 1
+    c.stride, c.P, c.Q = 2, 4, 4
+    assert lib.fpd_conv_f8_in_domain(c) == 0
+    assert lib.fpd_weight_quant_f8(None, 3, None) != 0 and 'null table' in err()
+    p = lib.fpd_plan_create()
+    assert lib.fpd_plan_add(p, R.OP_CONV_F8, R.C.byref(c8), R.C.sizeof(c8)) == 0
+    assert lib.fpd_plan_add(p, R.OP_CONV_F8, R.C.byref(c), R.C.sizeof(c)) < 0        # wrong args size for the op
+    lib.fpd_plan_destroy(p)
