@@ -230,3 +230,15 @@ def test_tools_fpd_train_cli_smoke_and_auto_resume(tmp_path):
     ck2 = torch.load(ckpts[0], map_location='cpu', weights_only=False)
     assert ck2['epoch'] == 3 and abs(ck2['optimizer']['param_groups'][0]['lr'] - 2.5e-6) < 1e-13   # second milestone (3 <= 2+1)
     assert float(ck2['optimizer']['state'][0]['step']) == 9
+    # every epoch validated (tools/fpd_train.py:266-285) and the best model was kept
+    assert log.count('Test: [0/') == 2 and 'PCK@0.5' in log
+    assert any(f == 'model_best.pth' for _, _, fs in os.walk(tmp_path) for f in fs)
+    # tools/test.py (reference tools/test.py:38-135): validation of the trained model from <output dir>/final_state.pth, flip test on
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), '--cfg', os.path.join(cfgd, 'hg4x128_student.yaml'),
+                         'OUTPUT_DIR', str(tmp_path), 'MODEL.EXTRA.NUM_FEATURES', '32', 'MODEL.EXTRA.NUM_STACKS', '2',
+                         'MODEL.IMAGE_SIZE', '128,128', 'MODEL.HEATMAP_SIZE', '32,32', 'TEST.BATCH_SIZE_PER_GPU', '8',
+                         'DATASET.NUM_VALID_SAMPLES', '16', 'MODEL.DTYPE', 'fp32', 'TEST.FLIP_TEST', 'True', 'TEST.SHIFT_HEATMAP', 'True',
+                         'TEST.POST_PROCESS', 'True', 'PRINT_FREQ', '1'], env=env, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, (r3.stdout[-1500:], r3.stderr[-3000:])
+    log3 = r3.stdout + r3.stderr
+    assert log3.count('Test: [') == 2 and 'validation done' in log3 and 'PCK@0.5' in log3
