@@ -11,6 +11,9 @@
 
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
+int fpd_conv_pp_option(int which, int value);
 int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
@@ -30,6 +33,10 @@ int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipS
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_partials(const fpd_wgrad_t& a);
+int fpd_wgrad_mfma_partials(const fpd_wgrad_t& a);
+int fpd_wgrad_naive_partials(const fpd_wgrad_t& a);
+int fpd_stem_wgrad_mfma_partials(const fpd_stem_t& a);
+int fpd_stem_wgrad_partials(const fpd_stem_t& a);
 int fpd_wreduce_launch(const fpd_wreduce_entry_t* table, int n, int64_t max_elems, hipStream_t st);
 int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
@@ -84,6 +91,13 @@ int fpd_set_backend(int32_t backend) {
     return prev;
 }
 
+int fpd_set_option(const char* name, int32_t value) {
+    FPD_REQUIRE(name, "set_option: null name");
+    if (!strcmp(name, "conv_pp")) return fpd_conv_pp_option(0, value);
+    if (!strcmp(name, "conv_pp_blocks")) return fpd_conv_pp_option(1, value);
+    return fpd_fail(-2, "set_option: unknown option '%s'", name);
+}
+
 int fpd_abi_sizeof(const char* n) {
 #define SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     SZ(fpd_bn_t); SZ(fpd_conv_t); SZ(fpd_wgrad_t); SZ(fpd_stem_t); SZ(fpd_ew_t); SZ(fpd_loss_t); SZ(fpd_adam_t);
@@ -108,7 +122,8 @@ static int validate_conv(const fpd_conv_t* a) {
 
 static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     int rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent ping-pong kernel
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_smallc_launch(*a, st);   // tiny input-channel counts (3, 17)
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
@@ -150,7 +165,8 @@ int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);
     if (rc == 1) {                       // not pairable: same result from two launches
         rc = dispatch_conv(&p->a, st);
         if (rc == 0) rc = dispatch_conv(&p->b, st);
@@ -213,16 +229,30 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->dtype == FPD_F32 || a->dtype == FPD_BF16, "wgrad: bad dtype %d", a->dtype);
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
+    FPD_REQUIRE(a->partial == nullptr || a->partial_stride >= (int64_t)a->K * a->R * a->S * a->C + a->K,
+                "wgrad: partial_stride %lld smaller than weight + bias", (long long)a->partial_stride);
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_tile_launch(*a, st);
-    FPD_REQUIRE(rc != 1 || a->partial == nullptr, "wgrad: partial slabs requested for a shape fpd_wgrad_num_partials() reports 0 for");
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
     return rc ? rc : check_launch();
 }
 
+/* slabs the kernel fpd_conv_wgrad() dispatches these dimensions to will write (same dispatch order as above) */
 int fpd_wgrad_num_partials(const fpd_wgrad_t* a) {
-    if (!a || g_fpd_backend != FPD_BACKEND_MFMA) return 0;
-    return fpd_wgrad_tile_partials(*a);
+    if (!a) return 0;
+    int n = 0;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_wgrad_tile_partials(*a);
+    if (n == 0 && g_fpd_backend != FPD_BACKEND_NAIVE) n = fpd_wgrad_mfma_partials(*a);
+    if (n == 0) n = fpd_wgrad_naive_partials(*a);
+    return n;
+}
+
+int fpd_stem_wgrad_num_partials(const fpd_stem_t* a) {
+    if (!a) return 0;
+    int n = 0;
+    if (g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_stem_wgrad_mfma_partials(*a);
+    if (n == 0) n = fpd_stem_wgrad_partials(*a);
+    return n;
 }
 
 int fpd_wgrad_reduce(const fpd_wreduce_entry_t* t, int32_t n, int64_t max_elems, fpd_stream_t stream) {
@@ -241,6 +271,8 @@ int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream) {
 
 int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->x && a->dy && a->dw, "stem wgrad: null pointer");
+    FPD_REQUIRE(a->partial == nullptr || a->partial_stride >= (int64_t)a->K * 148, "stem wgrad: partial_stride %lld smaller than weight + bias",
+                (long long)a->partial_stride);
     int rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_wgrad_mfma_launch(*a, (hipStream_t)stream);
     if (rc == 1) rc = fpd_stem_wgrad_launch(*a, (hipStream_t)stream);

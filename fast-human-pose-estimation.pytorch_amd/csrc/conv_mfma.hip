@@ -365,6 +365,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const fpd_wgrad_t a, co
     }
 
     const int R = a.R;
+    // no atomics: pixel chunk blockIdx.x stores its accumulator to slab blockIdx.x (a.partial), or -- without slabs the
+    // launch has a single chunk -- adds it straight into dw
+    float* slab = a.partial != nullptr ? a.partial + (size_t)blockIdx.x * a.partial_stride : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int t = wave + 4 * q;
@@ -374,11 +377,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const fpd_wgrad_t a, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int k = k0 + ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (k < K && c < C) atomicAdd(a.dw + ((size_t)(k * R + r) * S + s) * C + c, acc[q][i]);
+                if (k < K && c < C) {
+                    const size_t idx = ((size_t)(k * R + r) * S + s) * C + c;
+                    if (slab != nullptr) slab[idx] = acc[q][i];      // summed in a fixed order by fpd_wgrad_reduce()
+                    else a.dw[idx] += acc[q][i];                     // no slabs: ONE pixel chunk per launch owns the element
+                }
             }
         }
     }
-    if (do_bias && tid < kn) atomicAdd(a.dbias + k0 + tid, bsum);
+    if (do_bias && tid < kn) {
+        if (slab != nullptr) slab[(size_t)K * R * S * C + k0 + tid] = bsum;
+        else a.dbias[k0 + tid] += bsum;
+    }
 }
 
 template <typename T, int TN, int BK>
@@ -411,15 +421,32 @@ int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st) {
     return launch_conv_tn<float, 16>(a, st);
 }
 
-int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st) {
-    if (a.C % 16 != 0 || a.K % 16 != 0 || a.C > FPD_MAXC) return 1;
+// pixel chunks (= slabs) of the generic weight-gradient kernel and the pixels per chunk; 0 chunks = outside its domain
+static int wgrad_mfma_chunks(const fpd_wgrad_t& a, int& pch) {
+    if (a.C % 16 != 0 || a.K % 16 != 0 || a.C > FPD_MAXC) return 0;
     const int M = a.N * a.P * a.Q;
     const int taps = a.R * a.S, ktiles = cdiv(a.K, 128), ctiles = cdiv(a.C, 128);
     const int bkp = (a.dtype == FPD_BF16) ? 32 : 16;
     int chunks = cdiv(768, taps * ktiles * ctiles);
     chunks = std::max(1, std::min(chunks, cdiv(M, 4 * bkp)));
-    int pch = cdiv(cdiv(M, chunks), bkp) * bkp;
-    chunks = cdiv(M, pch);
+    pch = cdiv(cdiv(M, chunks), bkp) * bkp;
+    return cdiv(M, pch);
+}
+int fpd_wgrad_mfma_partials(const fpd_wgrad_t& a) {
+    int pch;
+    return wgrad_mfma_chunks(a, pch);
+}
+
+int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st) {
+    int pch = 0;
+    int chunks = wgrad_mfma_chunks(a, pch);
+    if (chunks == 0) return 1;
+    const int taps = a.R * a.S, ktiles = cdiv(a.K, 128), ctiles = cdiv(a.C, 128);
+    if (a.partial == nullptr) {              // no slabs: one chunk owns every element and adds into dw directly
+        const int bkp = (a.dtype == FPD_BF16) ? 32 : 16;
+        chunks = 1;
+        pch = cdiv(a.N * a.P * a.Q, bkp) * bkp;
+    }
     dim3 grid(chunks, taps, ktiles * ctiles);
     if (a.dtype == FPD_BF16)
         hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a, pch, ctiles);

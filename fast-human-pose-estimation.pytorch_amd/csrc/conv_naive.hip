@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
     }
 }
 
-// one thread per weight element and pixel chunk (blockIdx.y): serial loop over the chunk's pixels, one fp32 atomic per
-// thread at the end (dw / dbias are accumulators the caller zeroes).  Odd shapes: channel counts that are not multiples
+// one thread per weight element and pixel chunk (blockIdx.y): serial loop over the chunk's pixels, one plain store per
+// thread at the end (to its chunk's slab, or += into dw when the launch has a single chunk).  Odd shapes: channel counts that are not multiples
 // of 16 -- the 3-channel first convolution of HRNet (pose_hrnet.py:279), J = 17 heads, the scaled-down test networks.
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
@@ -122,8 +122,16 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(const fpd_wgrad_t a) {
         if (a.bn.mode != FPD_BN_NONE) xv = DT<T>::rnd(bn_act(xv, s_scale[c], s_shift[c], a.bn.relu));
         acc = fmaf(g, xv, acc);
     }
-    atomicAdd(a.dw + idx, acc);
-    if (a.dbias && c == 0 && r == 0 && s == 0) atomicAdd(a.dbias + k, bsum);
+    // no atomics: pixel chunk blockIdx.y stores to slab blockIdx.y (a.partial, summed by fpd_wgrad_reduce() in a fixed
+    // order); without slabs the launch has one chunk and adds into dw directly
+    if (a.partial != nullptr) {
+        float* slab = a.partial + (size_t)blockIdx.y * a.partial_stride;
+        slab[idx] = acc;
+        if (a.dbias && c == 0 && r == 0 && s == 0) slab[total + k] = bsum;
+    } else {
+        a.dw[idx] += acc;
+        if (a.dbias && c == 0 && r == 0 && s == 0) a.dbias[k] += bsum;
+    }
 }
 
 }  // namespace
@@ -140,11 +148,16 @@ int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st) {
     return 0;
 }
 
+static int wgrad_naive_chunks(const fpd_wgrad_t& a) {
+    const int M = a.N * a.P * a.Q;
+    return std::max(1, std::min(1024, M / 512));                      // >= 512 pixels per thread
+}
+int fpd_wgrad_naive_partials(const fpd_wgrad_t& a) { return a.C > FPD_MAXC ? 0 : wgrad_naive_chunks(a); }
+
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st) {
     if (a.C > FPD_MAXC) return fpd_fail(-3, "wgrad: channel count above %d", FPD_MAXC);
     const int total = a.K * a.R * a.S * a.C;
-    const int M = a.N * a.P * a.Q;
-    const int chunks = std::max(1, std::min(1024, M / 512));          // >= 512 pixels per thread
+    const int chunks = a.partial != nullptr ? wgrad_naive_chunks(a) : 1;
     if (a.dtype == FPD_BF16)
         hipLaunchKernelGGL((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
     else

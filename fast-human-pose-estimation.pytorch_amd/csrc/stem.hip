@@ -131,12 +131,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const fpd_stem_t a, con
         }
     }
     if (active) {
+        // no atomics: persistent block b -> slab b (a.partial), or a single block adding into dw directly
+        float* slab = a.partial != nullptr ? a.partial + (size_t)blockIdx.x * a.partial_stride : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXNT; ++i) {
             const int tap = tg + i * TG;
-            if (off[i] >= 0) atomicAdd(a.dw + (size_t)k * NTAP + tap, acc[i]);
+            if (off[i] >= 0) {
+                if (slab != nullptr) slab[(size_t)k * NTAP + tap] = acc[i];
+                else a.dw[(size_t)k * NTAP + tap] += acc[i];
+            }
         }
-        if (tg == 0 && a.dbias != nullptr) atomicAdd(a.dbias + k, bsum);
+        if (tg == 0 && a.dbias != nullptr) {
+            if (slab != nullptr) slab[(size_t)K * NTAP + k] = bsum;
+            else a.dbias[k] += bsum;
+        }
     }
 }
 
@@ -152,10 +160,15 @@ int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st) {
     return 0;
 }
 
+int fpd_stem_wgrad_partials(const fpd_stem_t& a) {
+    if (a.K > KMAX || 256 % a.K != 0) return 0;
+    return std::min(a.N * cdiv(a.P, TH) * cdiv(a.Q, TW), 1024);
+}
+
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st) {
     if (a.K > KMAX || 256 % a.K != 0) return fpd_fail(-3, "stem wgrad: K=%d must divide 256 and be <= %d", a.K, KMAX);
     const int tiles = a.N * cdiv(a.P, TH) * cdiv(a.Q, TW);
-    const int grid = std::min(tiles, 1024);
+    const int grid = a.partial != nullptr ? std::min(tiles, 1024) : 1;
     if (a.dtype == FPD_BF16)
         hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, tiles);
     else

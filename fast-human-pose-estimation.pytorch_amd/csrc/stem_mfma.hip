@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const fpd_stem_t a, 
     conv_epilogue_vec<bf16_t, TN>(c, acc, m0, 0, M, nullptr, reinterpret_cast<float*>(sA), reinterpret_cast<double*>(sA));
 }
 
-// grid-stride over pixel tiles; dW[k][tap] accumulated in registers, one atomic flush per block
+// grid-stride over pixel tiles; dW[k][tap] accumulated in registers, one flush per block (to its slab)
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a, const int logQ, const int mtiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LDD = 64 + 8;                                    // dy tile pitch (K <= 64)
@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a
             }
         }
     }
+    // no atomics: persistent block b stores its accumulator to slab b (a.partial; fpd_wgrad_reduce() adds the slabs in a
+    // fixed order), or -- no slabs: the launch is a single block -- adds it into dw directly
+    float* slab = a.partial != nullptr ? a.partial + (size_t)blockIdx.x * a.partial_stride : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int tt = wave + 4 * i;
@@ -231,11 +234,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int k = j * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (j < KT && k < K && tap < NTAP) atomicAdd(a.dw + (size_t)k * NTAP + tap, acc[i][j][e]);
+                    if (j < KT && k < K && tap < NTAP) {
+                        if (slab != nullptr) slab[(size_t)k * NTAP + tap] = acc[i][j][e];
+                        else a.dw[(size_t)k * NTAP + tap] += acc[i][j][e];
+                    }
                 }
         }
     }
-    if (a.dbias != nullptr && tid < K) atomicAdd(a.dbias + tid, bsum);
+    if (a.dbias != nullptr && tid < K) {
+        if (slab != nullptr) slab[(size_t)K * NTAP + tid] = bsum;
+        else a.dbias[tid] += bsum;
+    }
 }
 
 size_t patch_bytes(int logQ) {
@@ -273,6 +282,12 @@ int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     return 0;
 }
 
+int fpd_stem_wgrad_mfma_partials(const fpd_stem_t& a) {
+    int logQ;
+    if (!stem_mfma_ok(a, logQ)) return 0;
+    return std::min(a.N * a.P * a.Q / 128, 512);
+}
+
 int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     int logQ;
     if (!stem_mfma_ok(a, logQ)) return 1;
@@ -280,6 +295,6 @@ int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     const int tiles = a.N * a.P * a.Q / 128;
     static bool cfg = false;
     if (!cfg) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg = true; }
-    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(std::min(tiles, 512)), dim3(256), lds, st, a, logQ, tiles);
+    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(a.partial != nullptr ? std::min(tiles, 512) : 1), dim3(256), lds, st, a, logQ, tiles);
     return 0;
 }

@@ -8,7 +8,8 @@
 // fp32 MFMA takes one k per lane and reads the pixel-major tile directly.
 // A 512-thread block owns a 64x64 (bf16) / 32x32 (fp32) block of the K x C plane for ALL taps (8 waves, <= 5
 // accumulator tiles each, so two waves fit per SIMD and hide each other's staging / LDS latency),
-// walks pixel tiles persistently with register prefetch of the next tile, and flushes once with fp32 atomics.
+// walks pixel tiles persistently with register prefetch of the next tile, and flushes once: to a private slab that
+// fpd_wgrad_reduce() sums in a fixed order, or (no slabs given: one block per tile) straight into dw -- no atomics.
 // Replaces autograd of nn.Conv2d (weight/bias gradient) in /root/reference/lib/models/hourglass.py:20,23,27.
 #include <algorithm>
 #include <cstdlib>
@@ -247,10 +248,29 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     }
 
     // ---- flush ----
+    // No atomics anywhere: with slabs (a.partial) every persistent block stores its accumulator to its own slab and
+    // fpd_wgrad_reduce() adds the slabs in a fixed order; without slabs the launch has ONE block per (k, c) tile
+    // (gridDim.x == 1, see fpd_wgrad_tile_launch), which owns its dw / dbias elements and adds to them directly.
+    // Either way a weight gradient is a fixed-order sum: identical bytes run to run.
     if (dbg & 1) return;
+    const bool slabs = a.partial != nullptr;
+    if (KSPLIT && !slabs) {
+        // the two wave groups hold partial sums of the SAME elements: group 1 hands its accumulator over through LDS
+        float* s_x = reinterpret_cast<float*>(sH);       // >= (NW/2) * 64 * 16 floats: the tile region is free now
+        __syncthreads();
+        if (kgrp == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_x[((wave - NW / 2) * 16 + e) * 64 + lane] = acc[0][e];
+        }
+        __syncthreads();
+        if (kgrp == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] += s_x[(wave * 16 + e) * 64 + lane];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        if (slot_on[i]) {
+        if (slot_on[i] && (slabs || kgrp == 0)) {
             const int u = (KSPLIT ? wave % (NW / 2) : wave) + NW * i;
             const int tap = u / KC;
             const int c = c0 + ci * 32 + (lane & 31);
@@ -259,33 +279,33 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
                 const int k = k0 + ki * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (k < K && c < C) {
                     const size_t idx = ((size_t)k * RS + tap) * C + c;
-                    if (a.partial != nullptr) {
+                    if (slabs) {
                         // one slab per persistent block (two when the wave groups split the pixel steps)
                         float* slab = a.partial + (size_t)(blockIdx.x * (KSPLIT ? 2 : 1) + kgrp) * a.partial_stride;
                         slab[idx] = acc[i][e];
                     } else {
-                        atomicAdd(a.dw + idx, acc[i][e]);
+                        a.dw[idx] += acc[i][e];
                     }
                 }
             }
         }
     }
     if (do_bias) {
-        // block-level reduction of the per-thread partial sums first: every block of the grid targets the SAME K
-        // addresses, and same-address device atomics serialise (it was ~60 % of the 1x1 kernel time)
-        float* s_bias = reinterpret_cast<float*>(sD);
+        // block-level reduction of the per-thread partial sums in a FIXED order (parts 0 .. BPARTS-1 per channel)
+        float* s_bias = reinterpret_cast<float*>(sD);       // [BPARTS][CW]
         __syncthreads();
-        if (tid < CW) s_bias[tid] = 0.f;
-        __syncthreads();
-        atomicAdd(&s_bias[bch], bsum);
+        s_bias[bpart * CW + bch] = bsum;
         __syncthreads();
         if (tid < kn) {
-            if (a.partial != nullptr) {          // bias partials live behind the weight slab: [K*R*S*C .. +K)
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < BPARTS; ++q) tot += s_bias[q * CW + tid];
+            if (slabs) {                         // bias partials live behind the weight slab: [K*R*S*C .. +K)
                 const size_t boff = (size_t)K * RS * C + k0 + tid;
-                a.partial[(size_t)(blockIdx.x * (KSPLIT ? 2 : 1)) * a.partial_stride + boff] = s_bias[tid];
+                a.partial[(size_t)(blockIdx.x * (KSPLIT ? 2 : 1)) * a.partial_stride + boff] = tot;
                 if (KSPLIT) a.partial[(size_t)(blockIdx.x * 2 + 1) * a.partial_stride + boff] = 0.f;
             } else {
-                atomicAdd(a.dbias + k0 + tid, s_bias[tid]);
+                a.dbias[k0 + tid] += tot;
             }
         }
     }
@@ -340,7 +360,7 @@ int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
 // dw[i] += sum_b partial[b*stride + i]: second stage of the weight-gradient reduction for a table of convolutions
 __global__ __launch_bounds__(256) void wreduce_kernel(const fpd_wreduce_entry_t* table) {
     const fpd_wreduce_entry_t e = table[blockIdx.y];
-    const int64_t n4 = e.n >> 2;                 // n is a multiple of 4 (K*R*S*C with C % 16 == 0)
+    const int64_t n4 = e.n >> 2;                 // 16-byte vectors; the (rare) tail is handled below
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(e.dw + 4 * i);
         const float* p = e.partial + 4 * i;
@@ -350,6 +370,13 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const fpd_wreduce_entry_t*
             acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
         }
         *reinterpret_cast<f32x4*>(e.dw + 4 * i) = acc;
+    }
+    // tail (n not a multiple of 4: e.g. the 17 biases of an HRNet head)
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (e.n & 3)) {
+        const int64_t i = 4 * n4 + threadIdx.x;
+        float acc = e.dw[i];
+        for (int b = 0; b < e.count; ++b) acc += e.partial[(size_t)b * e.stride + i];
+        e.dw[i] = acc;
     }
 }
 
@@ -361,6 +388,7 @@ int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
     if (!wt_grid(a, g)) return 1;
     if (a.partial != nullptr && a.partial_stride < (int64_t)a.K * a.R * a.S * a.C + a.K)
         return fpd_fail(-2, "wgrad: partial_stride %lld smaller than weight + bias", (long long)a.partial_stride);
+    if (a.partial == nullptr) g.gx = 1;      // no slabs: one block per (k, c) tile adds straight into dw (deterministic, slow)
     if (a.R == 3) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 3, 128>(a, g, st) : launch_wt<float, 3, 128>(a, g, st);
     if (g.tp == 256) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 256>(a, g, st) : launch_wt<float, 1, 256>(a, g, st);
     return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 128>(a, g, st) : launch_wt<float, 1, 128>(a, g, st);

@@ -59,6 +59,40 @@ def _abuf(a):
     return None if a is None else (a.buf if isinstance(a, G.Act) else a)
 
 
+# FPD_WHATIF=token[,token...]: TIMING-ONLY experiments (results are wrong when set): the named class of ops is lowered to
+# no-ops, which shows what that class costs inside the pipelined step (tools/probes/r03_whatif.sh).  Student graph:
+# nowgrad / nowgrad_small / nowgrad_big (weight gradients, by map height <= 16 / >= 64), noapply (BN-backward applies),
+# nobigconv (convolutions on >= 64x64 maps), nobig / nomid / nosmall (every op on >= 64 / 32 / <= 16 high maps, weight
+# gradients excepted), noew.  Teacher graph: t_all, t_big, t_mid, t_small.
+_WHATIF = frozenset(t for t in os.environ.get('FPD_WHATIF', '').split(',') if t)
+
+
+def _whatif_drop(op, train):
+    k = op.kind
+    if k in ('conv2', 'bneck2', 'ew2'):
+        sub = op.a
+        k = sub.kind
+    else:
+        sub = op
+    dims = getattr(sub, 'dims', None)
+    h = dims[1] if dims else 0
+    if not train:
+        if k not in ('conv', 'bneck', 'head', 'ew', 'stem_fwd'):
+            return False
+        return ('t_all' in _WHATIF or ('t_big' in _WHATIF and h >= 64) or ('t_mid' in _WHATIF and h == 32) or
+                ('t_small' in _WHATIF and h <= 16))
+    if k in ('wgrad', 'stem_wgrad', 'wreduce'):
+        return ('nowgrad' in _WHATIF or ('nowgrad_small' in _WHATIF and k == 'wgrad' and h <= 16) or
+                ('nowgrad_big' in _WHATIF and k == 'wgrad' and h >= 64))
+    if k not in ('conv', 'ew', 'stem_fwd'):
+        return False
+    if k == 'ew' and ('noew' in _WHATIF or ('noapply' in _WHATIF and sub.op == 'bn_bwd_apply')):
+        return True
+    if k == 'conv' and 'nobigconv' in _WHATIF and h >= 64:
+        return True
+    return ('nobig' in _WHATIF and h >= 64) or ('nomid' in _WHATIF and h == 32) or ('nosmall' in _WHATIF and h <= 16)
+
+
 class Lowering:
     """IR op -> (native op code, ctypes struct)."""
 
@@ -197,6 +231,14 @@ class Lowering:
             s.w, s.bias, s.y, s.out_stats = p(op.w), p(op.bias), p(_abuf(op.y)), p(op.out_stats)
             return R.OP_STEM_FWD, s
         s.dy, s.dw, s.dbias = p(_abuf(op.dy)), p(op.dw), p(op.dbias)
+        s.partial, s.partial_stride = None, 0
+        if self.use_partials:                  # same two-stage reduction as the other weight gradients (no atomics)
+            n = R.lib().fpd_stem_wgrad_num_partials(C.byref(s))
+            if n > 0:
+                numel = op.dw.numel
+                stride = (numel + s.K + 63) // 64 * 64
+                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias]
+                self.partial_elems += n * stride
         return R.OP_STEM_WGRAD, s
 
     def ew(self, op):
@@ -247,6 +289,8 @@ class Lowering:
         return R.OP_MEMSET, s
 
     def op(self, op):
+        if _WHATIF and _whatif_drop(op, getattr(self, 'train', True)):
+            return R.OP_NOP, R.MemsetT()
         if op.kind == 'conv2':
             s = R.ConvPairT()
             s.a, s.b = self.conv(op.a, plain=True)[1], self.conv(op.b, plain=True)[1]
@@ -324,6 +368,7 @@ class GraphInstance:
                                       wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
         self.low = Lowering(self.A, self.dtype)
+        self.low.train = train
         self.plan = R.Plan()
         self.rng = {}
         self.graphs = {}

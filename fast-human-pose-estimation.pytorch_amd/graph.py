@@ -680,8 +680,10 @@ class HourglassGraph:
                         self.bwd[self.bwd.index(cont)] = cont.a
             elif op.kind == 'stem_fwd':
                 dy = op.y.grad
-                self.bwd.append(Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
-                                   dbias=self.p.grad('conv1.bias'), dims=op.dims, lane=1 + self.depth))
+                sw = Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
+                        dbias=self.p.grad('conv1.bias'), dims=op.dims, lane=1 + self.depth)
+                self.bwd.append(sw)
+                self._wg_bucket.append(sw)       # its slabs are summed by the bucket's 'wreduce' like every other weight gradient
             elif op.kind == 'ew':
                 self._ew_backward(op)
             elif op.kind == 'affsum':

@@ -68,7 +68,7 @@ class WgradT(C.Structure):
 class StemT(C.Structure):
     _fields_ = [('N', _i32), ('H', _i32), ('W', _i32), ('K', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32),
                 ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp), ('out_stats', _vp), ('dy', _vp),
-                ('dw', _vp), ('dbias', _vp)]
+                ('dw', _vp), ('dbias', _vp), ('partial', _vp), ('partial_stride', _i64)]
 
 
 class EwT(C.Structure):
@@ -186,6 +186,7 @@ SYMBOLS = {
     'fpd_wgrad_reduce': (C.c_int, [_vp, _i32, _i64, _vp]),
     'fpd_stem_forward': (C.c_int, [C.POINTER(StemT), _vp]),
     'fpd_stem_wgrad': (C.c_int, [C.POINTER(StemT), _vp]),
+    'fpd_stem_wgrad_num_partials': (C.c_int, [C.POINTER(StemT)]),
     'fpd_elementwise': (C.c_int, [C.POINTER(EwT), _vp]),
     'fpd_elementwise_pair': (C.c_int, [C.POINTER(EwPairT), _vp]),
     'fpd_pck': (C.c_int, [C.POINTER(PckT), _vp]),
@@ -216,6 +217,7 @@ SYMBOLS = {
     'fpd_plan_replay': (C.c_int, [_vp, _i32, _vp]),
     'fpd_last_error': (C.c_char_p, []),
     'fpd_set_backend': (C.c_int, [_i32]),
+    'fpd_set_option': (C.c_int, [C.c_char_p, _i32]),
     'fpd_abi_sizeof': (C.c_int, [C.c_char_p]),
     'fpd_abi_version': (C.c_int, []),
     'fpd_event_create': (_vp, []),
@@ -267,6 +269,14 @@ def check(rc, what=''):
 
 def set_backend(backend):
     return lib().fpd_set_backend(backend)
+
+
+def set_option(name, value):
+    """Process-wide run-time knob of the library (include/fpd_amd.h fpd_set_option); returns the previous value."""
+    prev = lib().fpd_set_option(name.encode(), int(value))
+    if prev < 0:
+        check(prev, 'fpd_set_option(%s)' % name)
+    return prev
 
 
 def current_stream():

@@ -140,7 +140,8 @@ typedef struct { fpd_conv_t a, b; } fpd_conv_pair_t;
 typedef struct { fpd_bneck_t a, b; } fpd_bneck_pair_t;
 
 /* Weight + bias gradient of the same conv (autograd of hourglass.py convs): dw[K][R][S][C] +=
- * sum_pixels dy * a(x), dbias[K] += sum_pixels dy.  fp32 atomics; caller zeroes dw/dbias. */
+ * sum_pixels dy * a(x), dbias[K] += sum_pixels dy; the caller zeroes dw/dbias.  DETERMINISTIC: no floating-point
+ * atomics -- every sum is formed in a fixed order, so two runs on the same inputs give identical bytes. */
 typedef struct {
     int32_t N, H, W, C, K, R, S, stride, pad, P, Q, dtype;
     const void* x;         /* forward input (pre-BN) */
@@ -148,9 +149,11 @@ typedef struct {
     float* dw;             /* [K][R][S][C] fp32 */
     float* dbias;          /* [K] or NULL */
     fpd_bn_t bn;           /* forward prologue, recomputed */
-    /* optional two-stage reduction: instead of flushing its accumulator into dw with device-scope atomics, persistent
-     * block b stores it to partial + b*partial_stride (layout of dw); fpd_wgrad_reduce() sums the slabs afterwards.
-     * The number of slabs the kernel will write for these dimensions is fpd_wgrad_num_partials() (0 = atomics only). */
+    /* two-stage reduction (what a training plan uses): block / pixel chunk b stores its accumulator to
+     * partial + b*partial_stride (layout of dw, bias partials behind it); fpd_wgrad_reduce() adds the slabs to dw in slab
+     * order afterwards.  The number of slabs written for these dimensions is fpd_wgrad_num_partials() (>= 1 for every
+     * supported shape).  partial == NULL: the launch uses ONE block per output element group, which adds into dw
+     * directly -- same result, no workspace, but no parallelism over the pixel axis (small problems / tests). */
     float* partial;
     int64_t partial_stride; /* floats between slabs, >= K*R*S*C + K (bias partials sit behind the weights) */
 } fpd_wgrad_t;
@@ -166,6 +169,8 @@ typedef struct {
     const void* dy;        /* wgrad: [N,P,Q,K] */
     float* dw;             /* wgrad: [K][7][7][3] */
     float* dbias;          /* wgrad: [K] */
+    float* partial;        /* wgrad: slabs of the two-stage reduction (see fpd_wgrad_t), fpd_stem_wgrad_num_partials() of them, or NULL */
+    int64_t partial_stride; /* floats between slabs, >= K*147 + K */
 } fpd_stem_t;
 
 /* Elementwise / pooling ops on NHWC tensors.  `op` selects the function:
@@ -293,6 +298,7 @@ int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writ
 int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, int64_t max_elems, fpd_stream_t stream);
 int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream);
 int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream);
+int fpd_stem_wgrad_num_partials(const fpd_stem_t* a);   /* slabs fpd_stem_wgrad writes when a->partial is set */
 int fpd_elementwise(const fpd_ew_t* a, fpd_stream_t stream);
 /* two independent elementwise ops of the same kind in one launch (else one after the other) */
 typedef struct { fpd_ew_t a, b; } fpd_ew_pair_t;
@@ -469,6 +475,10 @@ int fpd_plan_replay(fpd_plan* p, int32_t graph_id, fpd_stream_t stream);
 /* ---- misc ---- */
 const char* fpd_last_error(void);
 int fpd_set_backend(int32_t backend);         /* FPD_BACKEND_*; returns previous */
+/* run-time knobs (process-wide; the defaults are what the product uses): "conv_pp" = 0 never / 1 launches with >= 512 pixel
+ * tiles (default) / 2 whenever in its domain: use of the persistent ping-pong convolution kernel; "conv_pp_blocks" = its
+ * persistent grid (default 256).  Returns the previous value (>= 0), negative = unknown option. */
+int fpd_set_option(const char* name, int32_t value);
 int fpd_abi_sizeof(const char* struct_name);  /* sizeof of a struct above, -1 if unknown */
 int fpd_abi_version(void);
 /* in-stream timing helpers (HIP events on `stream`): returns elapsed ms of [start,stop) */

@@ -276,6 +276,6 @@ def test_gradient_buckets_are_contiguous_and_close_in_backward_order():
     # every weight gradient with a slab is reduced by exactly one bucket reduction, in its own bucket
     red = [o for o in g.bwd if o.kind == 'wreduce']
     seen = [id(w) for o in red for w in o.wgrads]
-    assert len(seen) == len(set(seen)) == sum(1 for o in g.bwd if o.kind == 'wgrad')
+    assert len(seen) == len(set(seen)) == sum(1 for o in g.bwd if o.kind in ('wgrad', 'stem_wgrad'))      # the stem's too: no atomics anywhere
     for o in red:
         assert all(table.bucket[w.dw.name[5:]] == o.bucket for w in o.wgrads)

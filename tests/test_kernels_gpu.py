@@ -61,6 +61,16 @@ class Bench:
         return self
 
     def run(self, ops, backend, partials=False):
+        if backend == 'pp' or (isinstance(backend, tuple) and backend[0] == 'pp'):
+            # the persistent ping-pong convolution (csrc/conv_pp.hip) forced for every in-domain bf16 shape; ('pp', n): n blocks,
+            # so that a block owns many tiles (uneven ranges, ragged last tiles, long ping-pong loops) even on small tensors
+            blocks = backend[1] if isinstance(backend, tuple) else 256
+            pm, pb = R.set_option('conv_pp', 2), R.set_option('conv_pp_blocks', blocks)
+            try:
+                return self.run(ops, 0, partials)
+            finally:
+                R.set_option('conv_pp', pm)
+                R.set_option('conv_pp_blocks', pb)
         if partials:                         # slab reduction of all weight gradients of the list (one gradient bucket)
             wg = [o for o in ops if o.kind == 'wgrad']
             ops = list(ops) + [G.Op('wreduce', bucket=0, wgrads=wg, bufs=[x for w in wg for x in (w.dw, w.dbias) if x is not None])]
@@ -147,7 +157,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('backend', BACKENDS + ['pp'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_forward(case, dtype, backend):
@@ -178,10 +188,106 @@ def test_conv_forward(case, dtype, backend):
         bt.compare(ostats, atol=TOL[dtype]['atol'] * scale, rtol=TOL[dtype]['rtol'], label='conv out_stats')
 
 
+# the persistent ping-pong kernel (csrc/conv_pp.hip) on shapes with many tiles per block: (N, H, W, C, K, R, bn, residual, blocks)
+PP_CASES = [
+    (4, 64, 64, 64, 64, 3, 'train', True, 8),        # student 3x3 @64^2: 16 tiles per block, 8 per group
+    (4, 64, 64, 64, 64, 3, 'train', False, 5),       # uneven tile ranges (128 tiles over 5 blocks)
+    (2, 64, 64, 128, 64, 1, 'train', False, 4),      # conv1 of a student Bottleneck
+    (2, 64, 64, 64, 128, 1, 'train', True, 8),       # conv3 (+ residual): K = 128 = two channel slabs per tile range
+    (2, 64, 64, 128, 128, 1, None, False, 16),       # fc / fc_
+    (2, 64, 64, 128, 16, 1, 'eval', False, 4),       # score: K = J = 16 (half-empty accumulator tile)
+    (2, 64, 64, 16, 128, 1, None, True, 4),          # score_: C = J = 16 (one k-step)
+    (1, 128, 128, 32, 32, 3, 'train', False, 6),     # layer1 @128^2: one image row per tile
+    (2, 128, 128, 32, 64, 1, 'train', True, 7),
+    (3, 20, 48, 32, 64, 3, 'train', True, 3),        # HRNet width 48: 96-pixel tiles, tiles straddling images (20 rows, 2 per tile)
+    (3, 9, 7, 16, 24, 3, 'train', True, 2),          # ragged everything: W = 7, K = 24, last tile partly outside the tensor
+    (1, 64, 64, 64, 64, 3, None, False, 256),        # more blocks than tile pairs
+]
+
+
+@pytest.mark.parametrize('case', PP_CASES)
+def test_conv_pp_forward(case):
+    N, H, W, C, K, Rr, bn_mode, use_res, blocks = case
+    pad = (Rr - 1) // 2
+    gen = torch.Generator().manual_seed(23 + sum(v for v in case if isinstance(v, int) and not isinstance(v, bool)))
+    bt = Bench(1)
+    x_val = rnd(gen, N, H, W, C) + 0.3
+    x = bt.act((N, H, W, C), x_val, 'x')
+    w = bt.buf('wlp', (K, Rr, Rr, C), rnd(gen, K, Rr, Rr, C, scale=1.0 / np.sqrt(C * Rr * Rr)))
+    bias = bt.buf('param', (K,), 0.1 * rnd(gen, K))
+    res = bt.act((N, H, W, K), rnd(gen, N, H, W, K), 'res') if use_res else None
+    y = bt.act((N, H, W, K), None, 'y')
+    bn = None
+    if bn_mode:
+        bn = make_bn(bt, gen, C, bn_mode)
+        bn.count = N * H * W
+        if bn_mode == 'train':
+            bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x_val.to(torch.bfloat16).float()))
+    ostats = bt.buf('stats', (RS, 2, K), torch.zeros(RS, 2, K, dtype=torch.float64))
+    op = G.Op('conv', x=x, w=w, wkey='w', bias=bias, bkey='b', residual=res, y=y, out_stats=ostats, bn=bn, epi='plain',
+              epi_x=None, epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, H, W))
+    bt.realise().run([op], ('pp', blocks))
+    bt.compare(y, label='conv_pp y %s' % (case,), **TOL[1])
+    bt.compare(ostats, atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='conv_pp out_stats')
+
+
+@pytest.mark.parametrize('case', [(4, 64, 64, 64, 64, 3, 8), (2, 64, 64, 64, 128, 1, 8), (2, 64, 64, 128, 64, 1, 5),
+                                  (1, 128, 128, 32, 32, 3, 6), (3, 20, 48, 32, 64, 3, 3), (2, 64, 64, 16, 128, 1, 4)])
+def test_conv_pp_dgrad(case):
+    """BatchNorm-backward epilogue (ReLU mask of epi_x + the two sums) of the ping-pong kernel, with an accumulate source
+    that aliases the output; forward convolution C -> K, i.e. the data gradient has K input and C output channels."""
+    N, H, W, C, K, Rr, blocks = case
+    pad = (Rr - 1) // 2
+    gen = torch.Generator().manual_seed(29 + sum(case))
+    bt = Bench(1)
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act((N, H, W, C), x_val, 'x')
+    dy = bt.act((N, H, W, K), rnd(gen, N, H, W, K), 'dy')
+    wm = bt.buf('param', (K, Rr, Rr, C), rnd(gen, K, Rr, Rr, C, scale=1.0 / np.sqrt(C * Rr * Rr)))
+    wb = bt.buf('wlp', (C, Rr, Rr, K))
+    prev = bt.act((N, H, W, C), 0.5 * rnd(gen, N, H, W, C), 'prev')
+    bn = make_bn(bt, gen, C, 'train')
+    bn.count = N * H * W
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x_val.to(torch.bfloat16).float()))
+    bst = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
+    ops = [G.Op('wprep', entries=[{'w': wm, 'w_fwd': None, 'w_bwd': wb}]),
+           G.Op('conv', x=dy, w=wb, wkey='w', bias=None, bkey=None, residual=prev, y=prev, out_stats=None, bn=None,
+                epi='bnrelu_bwd', epi_x=x, epi_bn=bn, epi_stats=bst, dims=(N, H, W, K, C, Rr, Rr, 1, Rr - 1 - pad, H, W))]
+    bt.realise().run(ops, ('pp', blocks))
+    bt.compare(prev, label='conv_pp dgrad dz %s' % (case,), **TOL[1])
+    bt.compare(bst, atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='conv_pp dgrad bn sums')
+
+
+def test_conv_pp_equals_conv_tile_bitwise():
+    """Both kernels round at the same points (fp32 accumulate, + residual, + bias, one rounding; statistics of the rounded
+    values), so on one tensor they must agree to the accumulation order of the MFMA chain: identical here because both
+    walk the taps and channel chunks in the same order."""
+    N, H, W, C, K = 2, 64, 64, 64, 64
+    gen = torch.Generator().manual_seed(31)
+    outs = []
+    for backend in (0, ('pp', 8)):
+        g2 = torch.Generator().manual_seed(31)
+        bt = Bench(1)
+        x_val = rnd(g2, N, H, W, C) + 0.3
+        x = bt.act((N, H, W, C), x_val, 'x')
+        w = bt.buf('wlp', (K, 3, 3, C), rnd(g2, K, 3, 3, C, scale=1.0 / np.sqrt(C * 9)))
+        bias = bt.buf('param', (K,), 0.1 * rnd(g2, K))
+        res = bt.act((N, H, W, K), rnd(g2, N, H, W, K), 'res')
+        y = bt.act((N, H, W, K), None, 'y')
+        bn = make_bn(bt, g2, C, 'train')
+        bn.count = N * H * W
+        bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x_val.to(torch.bfloat16).float()))
+        op = G.Op('conv', x=x, w=w, wkey='w', bias=bias, bkey='b', residual=res, y=y, out_stats=None, bn=bn, epi='plain',
+                  epi_x=None, epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, 3, 3, 1, 1, H, W))
+        bt.realise().run([op], backend)
+        outs.append(bt.gpu.view(y.buf).cpu().view(torch.int16).clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 DGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1), (2, 8, 8, 64, 128, 1, 0), (1, 6, 5, 16, 32, 3, 1), (2, 32, 32, 64, 64, 3, 1)]
 
 
-@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('backend', BACKENDS + ['pp', ('pp', 3)])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', DGRAD_CASES)
 def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
@@ -238,7 +344,7 @@ def test_conv_wgrad(case, dtype, backend):
     op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
     if backend == 'partials':          # default dispatch with the two-stage (slab + reduce) flush instead of atomics
         bt.realise().run([op], 0, partials=True)
-        assert bt.n_partial_ops == (1 if W >= 16 and W % (16 if dtype == 1 else 2) == 0 else 0)    # row tiles: k-steps stay in a row
+        assert bt.n_partial_ops == 1           # every weight-gradient kernel writes slabs (no floating-point atomics)
     else:
         bt.realise().run([op], backend)
     m = N * P * Q
@@ -247,7 +353,71 @@ def test_conv_wgrad(case, dtype, backend):
     bt.compare(db, label='wgrad dbias', **tol)
 
 
-@pytest.mark.parametrize('backend', [0, 1])
+@pytest.mark.parametrize('partials', [True, False])
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(8, 64, 64, 64, 64, 3, 1, True), (8, 64, 64, 128, 64, 1, 0, True), (32, 8, 8, 64, 64, 3, 1, True),
+                                  (32, 4, 4, 128, 64, 1, 0, True), (4, 32, 24, 3, 64, 3, 1, False), (4, 16, 12, 32, 17, 1, 0, False)])
+def test_conv_wgrad_is_bit_repeatable(case, dtype, partials):
+    """No floating-point atomics in any weight-gradient kernel (halo-tile, generic MFMA, direct): every sum is formed in a
+    fixed order -- slabs + fpd_wgrad_reduce, or a single block per output group when no slabs are given -- so repeated
+    runs on the same inputs give IDENTICAL bytes (deterministic reduction order)."""
+    N, H, W, C, K, Rr, pad, use_bn = case
+    if not partials and N * H * W > 16384:
+        pytest.skip('single-block flush: small problems only')
+    outs = []
+    for rep in range(3):
+        gen = torch.Generator().manual_seed(41 + sum(case[:7]))
+        bt = Bench(dtype)
+        x_val = rnd(gen, N, H, W, C)
+        x = bt.act((N, H, W, C), x_val, 'x')
+        dy = bt.act((N, H, W, K), rnd(gen, N, H, W, K, scale=0.1), 'dy')
+        dw = bt.buf('grad', (K, Rr, Rr, C), torch.zeros(K, Rr, Rr, C))
+        db = bt.buf('grad', (K,), torch.zeros(K))
+        bn = None
+        if use_bn:
+            bn = make_bn(bt, gen, C, 'train')
+            bn.count = N * H * W
+            xs = x_val.to(torch.bfloat16).float() if dtype == 1 else x_val
+            bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(xs))
+        op = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, H, W))
+        bt.realise().run([op], 0, partials=partials)
+        outs.append((bt.gpu.view(dw).cpu().clone(), bt.gpu.view(db).cpu().clone()))
+    for a, b in outs[1:]:
+        assert torch.equal(a.view(torch.int32), outs[0][0].view(torch.int32)), 'dw differs between identical runs'
+        assert torch.equal(b.view(torch.int32), outs[0][1].view(torch.int32)), 'dbias differs between identical runs'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem_wgrad_is_bit_repeatable(dtype):
+    N, H, W, K = 4, 128, 128, 32
+    outs = []
+    for rep in range(3):
+        gen = torch.Generator().manual_seed(43)
+        bt = Bench(dtype)
+        img = bt.buf('image', (N, 3, H, W), rnd(gen, N, 3, H, W))
+        dy = bt.act((N, H // 2, W // 2, K), rnd(gen, N, H // 2, W // 2, K, scale=0.1), 'dy')
+        dw = bt.buf('grad', (K, 7, 7, 3), torch.zeros(K, 7, 7, 3))
+        db = bt.buf('grad', (K,), torch.zeros(K))
+        sw = G.Op('stem_wgrad', image=img, dy=dy, dw=dw, dbias=db, dims=(N, H, W, K, H // 2, W // 2))
+        ops = [sw, G.Op('wreduce', bucket=0, wgrads=[sw], bufs=[dw, db])]
+        bt.realise()
+        low = E.Lowering(bt.gpu, dtype)
+        low.use_partials = True
+        plan = R.Plan()
+        lowered = [low.op(o) for o in ops]
+        low.finish_partials()
+        for code, st in lowered:
+            plan.add(code, st)
+        assert len(low.partials) == 1
+        plan.run(0, len(plan))
+        torch.cuda.synchronize()
+        outs.append((bt.gpu.view(dw).cpu().clone(), bt.gpu.view(db).cpu().clone()))
+    for a, b in outs[1:]:
+        assert torch.equal(a.view(torch.int32), outs[0][0].view(torch.int32))
+        assert torch.equal(b.view(torch.int32), outs[0][1].view(torch.int32))
+
+
+@pytest.mark.parametrize('backend', [0, 1, 'partials'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', [(2, 64, 64, 16), (1, 128, 96, 32), (2, 32, 48, 64), (2, 128, 128, 32), (1, 256, 256, 64)])
 def test_stem(case, dtype, backend):
@@ -263,9 +433,23 @@ def test_stem(case, dtype, backend):
     dy = bt.act((N, P, Q, K), rnd(gen, N, P, Q, K, scale=0.1), 'dy')
     dw = bt.buf('grad', (K, 7, 7, 3), torch.zeros(K, 7, 7, 3))
     db = bt.buf('grad', (K,), torch.zeros(K))
-    ops = [G.Op('stem_fwd', image=img, w=w, bias=b, y=y, out_stats=st, dims=(N, H, W, K, P, Q)),
-           G.Op('stem_wgrad', image=img, dy=dy, dw=dw, dbias=db, dims=(N, H, W, K, P, Q))]
-    bt.realise().run(ops, backend)
+    sw = G.Op('stem_wgrad', image=img, dy=dy, dw=dw, dbias=db, dims=(N, H, W, K, P, Q))
+    ops = [G.Op('stem_fwd', image=img, w=w, bias=b, y=y, out_stats=st, dims=(N, H, W, K, P, Q)), sw]
+    if backend == 'partials':           # slabs + reduction, as in a training plan
+        ops.append(G.Op('wreduce', bucket=0, wgrads=[sw], bufs=[dw, db]))
+        bt.realise()
+        PI.run(bt.cpu, ops)
+        low = E.Lowering(bt.gpu, dtype)
+        low.use_partials = True
+        plan = R.Plan()
+        lowered = [low.op(o) for o in ops]
+        low.finish_partials()
+        for code, s_ in lowered:
+            plan.add(code, s_)
+        plan.run(0, len(plan))
+        torch.cuda.synchronize()
+    else:
+        bt.realise().run(ops, backend)
     bt.compare(y, label='stem y', **TOL[dtype])
     bt.compare(st, atol=TOL[dtype]['atol'] * N * P * Q, rtol=TOL[dtype]['rtol'], label='stem stats')
     m = N * P * Q
@@ -509,9 +693,10 @@ PAIR_CASES = [
 ]
 
 
+@pytest.mark.parametrize('backend', [0, 'pp', ('pp', 6)])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', PAIR_CASES)
-def test_conv_pair(case, dtype):
+def test_conv_pair(case, dtype, backend):
     """'conv2' op (one launch) vs the interpreter running the two convolutions one after the other."""
     N, H, W, C, K, R, bnm, epi = case
     gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -543,7 +728,7 @@ def test_conv_pair(case, dtype):
                          dims=(N, h, w, C, K, R, R, 1, (R - 1) // 2, h, w), **kw))
     op = G.Op('conv2', a=subs[0], b=subs[1])
     b.realise()
-    b.run([op], 0)
+    b.run([op], backend)
     for i, s in enumerate(subs):
         b.compare(s.y, label='pair[%d] y %r' % (i, case), **TOL[dtype])
         st = s.out_stats if s.out_stats is not None else s.epi_stats
