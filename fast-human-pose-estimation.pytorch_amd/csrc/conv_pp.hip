@@ -1,28 +1,28 @@
-// conv_pp: PERSISTENT "ping-pong" convolution for the big feature maps of the student chain (bf16, stride-1 1x1 / 3x3
-// "same" convolutions with C, K <= 128: every train-mode convolution and data gradient of the hourglass at 64x64 and
-// 128x128, where a launch has >= 512 pixel tiles).  Same contract as conv_tile_kernel (fpd_conv_t): BatchNorm+ReLU
-// prologue on the operand, bias / residual, batch statistics of the result or the BN-backward epilogue.
+// conv_pp: PERSISTENT convolution for the big feature maps of the student chain (bf16, stride-1 1x1 / 3x3 "same"
+// convolutions with C, K <= 128: the train-mode convolutions and data gradients of the hourglass at 64x64 and 128x128,
+// where a launch has >= 512 pixel tiles).  Same contract as conv_tile_kernel (fpd_conv_t): BatchNorm+ReLU prologue on
+// the operand, bias / residual, batch statistics of the result or the BN-backward epilogue.
 //
-// Why a second kernel: conv_tile runs load -> stage -> MFMA -> epilogue serially inside every block and re-fetches the
-// weight tiles per tap and block, so at 64x64 a convolution takes 24-34 us against a 7-17 us HBM bound (DESIGN.md
-// section 5, r02 ablation).  Here
-//   * a block is resident for the whole launch (<= 1 per CU, 8 wave64) and owns a contiguous range of pixel tiles;
-//   * ALL weights of the convolution (<= 72 KB: 3x3 64->64) are staged into LDS ONCE per block, XOR-swizzled
-//     (16-byte chunk c of row n sits at c ^ sw(n)) so that the unpadded rows are read without bank conflicts;
-//   * the 8 waves form two groups of 4 that work on alternating tiles half a period apart ("ping-pong"): while one
-//     group issues the MFMAs of its tile (phase X), the other one runs the epilogue of its previous tile and stages its
-//     next one (phase Y) -- matrix pipe beside VALU / LDS stores / global stores on every SIMD; the next tile's operand
-//     rows and the epilogue's residual / epi_x vectors are requested at the start of X and consumed in Y (a full phase
-//     of latency cover, loads survive the barriers);
-//   * the MFMAs run transposed (first operand = weights): a lane owns 4 consecutive channels of one pixel, the
-//     accumulators go through a wave-private fp32 LDS staging area and leave as 16-byte vectors in full 128-byte lines;
-//   * statistics are accumulated per thread over all tiles of the block and flushed once per block;
-//   * a block computes a slab of <= 64 output channels (K = 128: two slabs = two blocks per tile range, placed on the same
-//     XCD so that the second one finds the operand rows in that L2): 32 accumulator registers per lane, and everything a
-//     thread keeps across the phases (operand prefetch 32, residual / epi_x prefetch 16 + 16, statistics 24) fits the
-//     256-register budget of two waves per SIMD without spills.
-// Every phase is split in two halves by a block-wide barrier (X1 | X2 beside Y1 | Y2): Y1's staging area aliases the
-// group's operand image, which Y2 then overwrites with the next tile.
+// Why a second kernel: conv_tile re-fetches the weight tiles per tap and block, flushes statistics per 128-pixel block
+// and stages its epilogue with 4-byte LDS stores, so at 64x64 a convolution takes 24-34 us against a 7-17 us HBM bound
+// (DESIGN.md section 5, r02 ablation: the epilogue alone is 12-19 us).  Here
+//   * a block (8 wave64) is resident for the whole launch and walks a contiguous range of pixel tiles; up to two blocks
+//     share a CU (<= 128 registers per lane, LDS permitting), so one block's barriers / memory waits are the other's
+//     issue slots;
+//   * ALL weights of its <= 64-channel output slab (<= 72 KB: 3x3 64->64) are staged into LDS ONCE per block,
+//     XOR-swizzled (16-byte chunk c of row n sits at c ^ sw(n)): unpadded rows, conflict-free b128 fragment reads;
+//   * the next tile's operand rows are requested as soon as the current tile is staged (in flight during its MFMAs
+//     and epilogue; global loads survive the barriers), all loads are issued branch-free (clamped addresses, validity
+//     kept as a bit mask);
+//   * the MFMAs run transposed (first operand = weights): a lane owns 4 consecutive channels of one pixel, so the
+//     accumulators go to a WAVE-PRIVATE fp32 LDS staging tile as 16-byte stores and leave as 16-byte vectors of
+//     8 channels (+ residual + bias, one rounding -- the same rounding points as conv_tile);
+//   * statistics are accumulated per thread over all tiles of the block and flushed once per block.
+// An 8-wave block computes 128 pixels x 64 channels per tile (4 pixel groups x 2 channel halves), or 256 pixels x 32
+// channels when K <= 32.  K = 128: two slabs = two blocks per tile range, 8 block ids apart (same XCD: its L2 serves
+// the operand rows to the second slab).  A first version split the 8 waves into two groups working half a period
+// apart (MFMA of one beside the epilogue / staging of the other): correct, but the VALU-heavy half ran at 1 wave per
+// SIMD and bounded the tile (profiles/r03_conv_pp_stamps.txt); all waves on every phase + two blocks per CU is faster.
 //
 // Replaces the same reference calls as conv_tile (nn.Conv2d + BatchNorm2d + ReLU, /root/reference/lib/models/hourglass.py:18-52).
 #include <algorithm>
@@ -36,62 +36,62 @@ namespace {
 constexpr int pp_ilog2(int v) { return v <= 1 ? 0 : 1 + pp_ilog2(v / 2); }
 
 struct PPGeo {
-    int nrows;                // image rows per tile (tile = nrows * W <= 128 pixels)
+    int nrows;                // image rows per tile
     int ntiles;               // pixel tiles of this convolution
-    int nblk;                 // persistent blocks working on it
-    int region;               // bytes of one group's LDS region (operand image / epilogue staging), multiple of 16
+    int nblk;                 // tile ranges (persistent blocks per channel slab) working on it
+    int region;               // bytes of the LDS region holding the operand image / the epilogue staging tiles, multiple of 16
     unsigned mW, mWV, mH;     // multiply-high reciprocals of W, W * (C / 8), H
 };
 __device__ __forceinline__ int pp_qdiv(int v, unsigned magic) { return (int)__umulhi((unsigned)v, magic); }
 static inline unsigned pp_magic(int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); }
 
-// launder a value: everything derived from it is recomputed where it is used instead of being hoisted out of the phase loop
-// and kept in registers for the whole kernel (the register budget is what bounds this kernel, not a few VALU operations)
+// launder a value: everything derived from it is recomputed where it is used instead of being hoisted out of the tile loop
+// and kept in registers for the whole kernel (the register budget bounds this kernel, not a few VALU operations)
 __device__ __forceinline__ int pp_fresh(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
 
 #ifdef FPD_PP_TIMING      // probe build only (tools/probes): cycle stamps of two blocks at the phase boundaries, printed by the kernel
-#define PP_STAMP() do { if ((tid & 255) == 0 && s_ns < 60) s_stamp[grp * 60 + s_ns++] = clock64(); } while (0)
+#define PP_STAMP() do { if (tid == 0 && s_ns < 100) s_stamp[s_ns++] = clock64(); } while (0)
 #else
 #define PP_STAMP() do { } while (0)
 #endif
 
-template <int R, int C, int TN, bool BWD>
+// KH = 2: tile = 128 pixels x 64 channels (wave = pixel group w % 4, channel half w / 4); KH = 1: 256 pixels x 32 channels
+template <int R, int C, int KH, bool BWD>
 __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo geo, const int bi, const int n0) {
-    constexpr int RS = R * R, KP = 32 * TN, CPR = C / 8, LOG_CPR = pp_ilog2(CPR), KS = C / 16;
+    constexpr int RS = R * R, KP = 32 * KH, PXW = 8 / KH, CPR = C / 8, LOG_CPR = pp_ilog2(CPR), KS = C / 16;
     constexpr int LDA = C * 2 + 16;                       // operand-image pixel pitch in BYTES (16 B pad: conflict-free b128 reads)
-    constexpr int CVN = KP / 8, RPI = 64 / CVN, NIT = 32 / RPI;     // 8-channel chunks, rows per read-back step, steps
-    constexpr int LDST = KP * 4 + 16;                     // staging pitch in bytes (fp32)
-    constexpr int NVH = 8;                                // operand vectors per thread and tile (host guarantees the fit)
+    constexpr int LDST = 32 * 4 + 16;                     // pitch of a wave's [32 px][32 ch] fp32 staging tile
+    constexpr int NVH = 4;                                // operand vectors per thread and tile (host guarantees the fit)
     constexpr int pad = (R - 1) / 2;
     constexpr int RPB = CPR >= 16 ? 1 : 16 / CPR;         // weight rows per 256-byte bank row
     constexpr int NWV = (KP * RS * CPR + 511) / 512;      // weight vectors per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);        // 0 / 1: wave-uniform
-    const int tg = tid & 255, wq = (tid >> 6) & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave % PXW, hc = wave / PXW;           // pixel group / channel half of this wave
     const int H = a.H, W = a.W, K = a.K;
     const int M = a.N * H * W, GR = a.N * H;
     const int nrows = geo.nrows, hrows = nrows + R - 1, WP = W + R - 1;
-    const int TPX = nrows * W;
+    const int TPX = nrows * W;                            // pixels per tile (<= 32 * PXW)
     const int zero_px = hrows * WP;
-#ifdef FPD_PP_TIMING
-    long long* s_stamp = reinterpret_cast<long long*>(smem + (2 * C + 5 * KP) * 4 + RS * KP * C * 2 + 2 * geo.region);
-    int s_ns = 0;
-    if (tid < 120) s_stamp[tid] = 0;
-    __syncthreads();
-#endif
-    PP_STAMP();
 
     float* s_scale = reinterpret_cast<float*>(smem);      // [C]
     float* s_shift = s_scale + C;                         // [C]
     float* s_epi = s_shift + C;                           // [4][KP] (BNRELU_BWD)
     float* s_bias = s_epi + 4 * KP;                       // [KP]
     unsigned char* sW = reinterpret_cast<unsigned char*>(s_bias + KP);
-    unsigned char* sG = sW + RS * KP * C * 2 + grp * geo.region;     // this group's region
+    unsigned char* sG = sW + RS * KP * C * 2;             // operand image; the waves' epilogue staging tiles alias it
+#ifdef FPD_PP_TIMING
+    long long* s_stamp = reinterpret_cast<long long*>(sG + geo.region);
+    int s_ns = 0;
+    if (tid < 100) s_stamp[tid] = 0;
+    __syncthreads();
+#endif
+    PP_STAMP();
     const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
     const bf16_t* __restrict__ w = reinterpret_cast<const bf16_t*>(a.w);
     bf16_t* __restrict__ y = reinterpret_cast<bf16_t*>(a.y);
@@ -99,53 +99,51 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const bf16_t* ex = reinterpret_cast<const bf16_t*>(a.epi_x);
     const bool want_stats = BWD || (a.out_stats != nullptr);
 
-    // ---- this block's tiles: a contiguous range; group g takes every other one ----
+    // ---- this block's tiles: a contiguous range ----
     const int t_beg = (int)((long long)bi * geo.ntiles / geo.nblk);
     const int t_end = (int)((long long)(bi + 1) * geo.ntiles / geo.nblk);
-    const int nt = t_end - t_beg;
-    const int n_g = (nt + 1 - grp) >> 1;
-    const int nint = max(2 * ((nt + 1) >> 1), (nt >> 1) > 0 ? 2 * (nt >> 1) + 1 : 0);
 
-    // ---- operand staging (one group = 256 threads; a thread always stages the same 8 channels: 256 % CPR == 0) ----
+    // ---- operand staging: vector v = tid + 512 i of the tile's hrows x W x CPR operand vectors (a thread always stages the
+    //      same 8 channels: 512 % CPR == 0).  Loads are unconditional (rows outside the tensor: clamped address, cleared bit).
     const int WV = W * CPR, nvtot = hrows * WV;
+    const int nvh = (nvtot + 511) >> 9;                   // uniform trip count
     uint4 rh[NVH];
     unsigned hmask = 0;
     auto halo_load = [&](int tile) {
-        const int g0 = tile * nrows;
-        const int tgl = pp_fresh(tg);
-        const int cve = (tgl & (CPR - 1)) * 8;
+        const int g0 = tile * nrows - pad;
+        const int tl = pp_fresh(tid);
+        const int cve = (tl & (CPR - 1)) * 8;
         hmask = 0;
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            const int v = tgl + i * 256;
-            rh[i] = make_uint4(0, 0, 0, 0);
-            if (v < nvtot) {
+            if (i < nvh) {
+                const int v = min(tl + i * 512, nvtot - 1);
                 const int hr = pp_qdiv(v, geo.mWV);
                 const int j = (v - hr * WV) >> LOG_CPR;
-                const int g = g0 - pad + hr;
-                if ((unsigned)g < (unsigned)GR) {
-                    rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(g * W + j) * C + cve));
-                    hmask |= 1u << i;
-                }
+                const int g = g0 + hr;
+                const int gc = min(max(g, 0), GR - 1);
+                rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(gc * W + j) * C + cve));
+                hmask |= (g == gc ? 1u : 0u) << i;
             }
         }
     };
     const float relu_lo = a.bn.relu ? 0.f : -3.4e38f;
     auto halo_store = [&]() {
-        const int tgl = pp_fresh(tg);
-        const int cvb = (tgl & (CPR - 1)) * 16;
-        // the zero border columns and zero pixels first (the epilogue staging of the previous tile overwrote them)
+        const int tl = pp_fresh(tid);
+        const int cvb = (tl & (CPR - 1)) * 16;
+        // zero border columns and zero pixels first (the epilogue staging of the previous tile overwrote them)
         {
             const uint4 z = make_uint4(0, 0, 0, 0);
             const int nb = (R == 3) ? 2 * hrows : 0;
-            for (int v = tgl; v < (nb + 3) * CPR; v += 256) {
+            for (int v = tl; v < (nb + 3) * CPR; v += 512) {
                 const int pz = v >> LOG_CPR, cv = (v & (CPR - 1)) * 16;
                 const int px = pz < nb ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - nb);
                 *reinterpret_cast<uint4*>(sG + px * LDA + cv) = z;
             }
         }
         f32x4 sc0, sc1, sh0, sh1;
-        if (a.bn.mode != FPD_BN_NONE) {
+        const bool has_bn = a.bn.mode != FPD_BN_NONE;
+        if (has_bn) {
             sc0 = *reinterpret_cast<const f32x4*>(s_scale + (cvb >> 1));
             sc1 = *reinterpret_cast<const f32x4*>(s_scale + (cvb >> 1) + 4);
             sh0 = *reinterpret_cast<const f32x4*>(s_shift + (cvb >> 1));
@@ -153,12 +151,13 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            const int v = tgl + i * 256;
-            if (v < nvtot) {
-                const int hr = pp_qdiv(v, geo.mWV);
-                const int j = (v - hr * WV) >> LOG_CPR;
+            if (i < nvh) {
+                const int v = tl + i * 512;
+                const int vc = min(v, nvtot - 1);
+                const int hr = pp_qdiv(vc, geo.mWV);
+                const int j = (vc - hr * WV) >> LOG_CPR;
                 uint4 val = rh[i];
-                if (a.bn.mode != FPD_BN_NONE) {
+                if (has_bn) {
                     float f[8];
                     DT<bf16_t>::unpack(val, f);
 #pragma unroll
@@ -167,15 +166,18 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                         f[4 + e] = fmaxf(fmaf(f[4 + e], sc1[e], sh1[e]), relu_lo);
                     }
                     val = DT<bf16_t>::pack(f);
-                    if (!((hmask >> i) & 1u)) val = make_uint4(0, 0, 0, 0);      // rows outside the tensor stay exactly zero
+                    const bool in = (hmask >> i) & 1u;    // rows outside the tensor stay exactly zero
+                    val.x = in ? val.x : 0u; val.y = in ? val.y : 0u; val.z = in ? val.z : 0u; val.w = in ? val.w : 0u;
                 }
-                *reinterpret_cast<uint4*>(sG + (hr * WP + j + pad) * LDA + cvb) = val;
+                // threads past the last vector of a ragged tile write to the spare 16 bytes behind the zero pixels
+                const int dst = v < nvtot ? (hr * WP + j + pad) * LDA + cvb : (zero_px + 3) * LDA;
+                *reinterpret_cast<uint4*>(sG + dst) = val;
             }
         }
     };
 
     // ---- prologue: first operand rows, then the weights, requested before anything else ----
-    if (n_g > 0) halo_load(t_beg + grp);
+    if (t_beg < t_end) halo_load(t_beg);
     {
         uint4 rw[NWV];
 #pragma unroll
@@ -202,8 +204,6 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     PP_STAMP();
     __syncthreads();                                      // tables + weights visible
     PP_STAMP();
-    if (n_g > 0) halo_store();
-    PP_STAMP();
 
     // ---- per-lane MFMA addressing ----
     const int ml = wq * 32 + l31;                         // pixel of the tile this lane feeds (second MFMA operand)
@@ -223,223 +223,218 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         }
     };
 
-    f32x16 acc[TN];
-    // steps [lo, hi) of the tap x k-step sequence of one tile.  Weight fragment of (tap, tn, kk): row tn*32 + l31 of tile `tap`,
-    // 16-byte chunk (2 kk + hh) ^ sw(row); sw(row) is the same for rows l31 + 32 tn.
-    auto mma_steps = [&](const int lo, const int hi) {
-        const int l31f = pp_fresh(l31);
-        const unsigned char* wrow = sW + l31f * (C * 2);
-        const int wsw = (l31f / RPB) & (CPR - 1);
-#pragma unroll
-        for (int st = 0; st < RS * KS; ++st) {
-            if (st < lo || st >= hi) continue;
-            const int tap = st / KS, kk = st - tap * KS;
-            const int r = tap / R, s = tap - r * R;
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sG + ab[r] + s * LDA + kk * 32 + hh * 16);
-            const int wo = ((2 * kk + hh) ^ wsw) * 16;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + (tap * KP + tn * 32) * (C * 2) + wo);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[tn], 0, 0, 0);
-            }
-        }
-    };
-    constexpr int NSTEP = RS * KS, HALF = (NSTEP + 1) / 2;
-
-    // ---- epilogue state: a lane reads back the 8-channel chunk cvl of pixel rows row0, row0 + RPI, ... of its wave's 32 pixels ----
-    uint4 rres[NIT], rex[BWD ? NIT : 1];
+    // ---- epilogue state: a lane reads back the 8-channel chunk cv4 of rows r16, r16 + 16 of its wave's 32 px x 32 ch block ----
+    uint4 rres[2], rex[BWD ? 2 : 1];
     float f1[8], f2[8], cshift[8];
     int nrow = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { f1[e] = 0.f; f2[e] = 0.f; cshift[e] = 0.f; }
     const float relu_gate = a.epi_bn.relu ? 0.f : -3.4e38f;
-    auto request = [&](int tile) {                        // residual / epi_x vectors of the tile whose MFMAs start now
-        const int m0 = tile * TPX;
+    const int kw0 = n0 + hc * 32;                         // first channel of this wave's block
+    auto request = [&](int tile) {                        // residual / epi_x vectors of `tile`
         const int ln = pp_fresh(lane);
-        const int cvl = ln % CVN, row0 = ln / CVN;
+        const int cv4 = ln & 3, r16 = ln >> 2;
+        const int k0 = min(kw0 + cv4 * 8, K - 8);         // (clamped: channel chunks past K are never stored)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int px = wq * 32 + row0 + RPI * it;
-            const int m = m0 + px, k0 = n0 + cvl * 8;
-            rres[it] = make_uint4(0, 0, 0, 0);
-            if (BWD) rex[it] = make_uint4(0, 0, 0, 0);
-            if (px < TPX && m < M && k0 < K) {
-                const size_t off = (size_t)m * K + k0;
-                if (res != nullptr) rres[it] = *reinterpret_cast<const uint4*>(res + off);
-                if (BWD) rex[it] = *reinterpret_cast<const uint4*>(ex + off);
-            }
+        for (int it = 0; it < 2; ++it) {
+            const int m = min(tile * TPX + wq * 32 + r16 + 16 * it, M - 1);
+            const size_t off = (size_t)m * K + k0;
+            if (res != nullptr) rres[it] = *reinterpret_cast<const uint4*>(res + off);
+            if (BWD) rex[it] = *reinterpret_cast<const uint4*>(ex + off);
         }
     };
-    auto epilogue = [&](int tile) {
-        const int m0 = tile * TPX;
+    f32x16 acc;
+    auto epilogue = [&](int tile, const bool first) {
         const int ln = pp_fresh(lane);
-        const int cvl = ln % CVN, row0 = ln / CVN;
-        unsigned char* stg = sG + wq * (32 * LDST);       // wave-private [32 px][LDST]
+        const int cv4 = ln & 3, r16 = ln >> 2;
+        unsigned char* stg = sG + wave * (32 * LDST);     // wave-private [32 px][LDST]
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[tn][4 * j + e];
-                *reinterpret_cast<f32x4*>(stg + l31 * LDST + (tn * 32 + 8 * j + 4 * hh) * 4) = v;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[4 * j + e];
+            *reinterpret_cast<f32x4*>(stg + l31 * LDST + (8 * j + 4 * hh) * 4) = v;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's staging stores are in the LDS
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_bias + cvl * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_bias + cvl * 8 + 4);
-        float esc[8], esh[8], emu[8], eis[8];
-        if (BWD) {
+        const int kl = hc * 32 + cv4 * 8;                 // channel chunk inside the slab
+        const int k0 = n0 + kl;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = r16 + 16 * it;
+            const int px = wq * 32 + row;
+            const int m = tile * TPX + px;
+            const bool ok = px < TPX && m < M && k0 < K;
+            const float live = ok ? 1.f : 0.f;
+            const unsigned rr[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
+            const unsigned xr[4] = {rex[BWD ? it : 0].x, rex[BWD ? it : 0].y, rex[BWD ? it : 0].z, rex[BWD ? it : 0].w};
+            unsigned pw[4];
+            // 4 channels at a time; the per-channel tables are re-read from the LDS (laundered address) instead of living in
+            // registers across the tile loop: v = acc + residual + bias, rounded once
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(s_epi + cvl * 8 + 4 * q);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(s_epi + KP + cvl * 8 + 4 * q);
-                const f32x4 t2 = *reinterpret_cast<const f32x4*>(s_epi + 2 * KP + cvl * 8 + 4 * q);
-                const f32x4 t3 = *reinterpret_cast<const f32x4*>(s_epi + 3 * KP + cvl * 8 + 4 * q);
+                const int klq = pp_fresh(kl) + 4 * q;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * LDST + cv4 * 32 + 16 * q);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(s_bias + klq);
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { esc[4 * q + e] = t0[e]; esh[4 * q + e] = t1[e]; emu[4 * q + e] = t2[e]; eis[4 * q + e] = t3[e]; }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int row = row0 + RPI * it;
-            const int px = wq * 32 + row;
-            const int m = m0 + px, k0 = n0 + cvl * 8;
-            if (px < TPX && m < M && k0 < K) {
-                float v[8];
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(stg + row * LDST + cvl * 32);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(stg + row * LDST + cvl * 32 + 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
-                const size_t off = (size_t)m * K + k0;
+                for (int e = 0; e < 4; ++e) v[e] = t[e];
                 if (res != nullptr) {
-                    float r8[8];
-                    DT<bf16_t>::unpack(rres[it], r8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned wd = rr[2 * q + (e >> 1)];
+                        v[e] += __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                for (int e = 0; e < 4; ++e) v[e] += bq[e];
                 if (BWD) {
-                    float xv[8], vr[8];
-                    DT<bf16_t>::unpack(rex[it], xv);
+                    // ReLU mask of the forward tensor + the two BatchNorm-backward sums
+                    const float* te = s_epi + klq;
+                    const f32x4 esc = *reinterpret_cast<const f32x4*>(te);
+                    const f32x4 esh = *reinterpret_cast<const f32x4*>(te + KP);
+                    const f32x4 emu = *reinterpret_cast<const f32x4*>(te + 2 * KP);
+                    const f32x4 eis = *reinterpret_cast<const f32x4*>(te + 3 * KP);
+                    float xv[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned wd = xr[2 * q + (e >> 1)];
+                        xv[e] = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
                         const float z = fmaf(xv[e], esc[e], esh[e]);
                         v[e] = (z > relu_gate) ? v[e] : 0.f;
                     }
-                    const uint4 pk = DT<bf16_t>::pack(v);
-                    DT<bf16_t>::unpack(pk, vr);                      // the stored (rounded) gradient is what gets summed
+                    pw[2 * q] = f2bf_pk(v[0], v[1]);
+                    pw[2 * q + 1] = f2bf_pk(v[2], v[3]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        f1[e] += vr[e];
-                        f2[e] = fmaf(vr[e], (xv[e] - emu[e]) * eis[e], f2[e]);
+                    for (int e = 0; e < 4; ++e) {                    // the stored (rounded) gradient is what gets summed
+                        const unsigned wd = pw[2 * q + (e >> 1)];
+                        const float g = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16)) * live;
+                        f1[4 * q + e] += g;
+                        f2[4 * q + e] = fmaf(g, (xv[e] - emu[e]) * eis[e], f2[4 * q + e]);
                     }
-                    *reinterpret_cast<uint4*>(y + off) = pk;
                 } else {
-                    const uint4 pk = DT<bf16_t>::pack(v);
+                    pw[2 * q] = f2bf_pk(v[0], v[1]);
+                    pw[2 * q + 1] = f2bf_pk(v[2], v[3]);
                     if (want_stats) {
-                        float vr[8];
-                        DT<bf16_t>::unpack(pk, vr);
-                        if (nrow == 0) {
+                        if (first && it == 0) {
+                            // the shift of the shifted sums must be COMMON to the 16 lanes that own a channel chunk: the rounded
+                            // value of the wave's first pixel row (lanes r16 == 0 hold it), handed over through the LDS
+                            float* sh = reinterpret_cast<float*>(stg) + cv4 * 8 + 4 * q;      // (row 0 of the staging tile was read above)
+                            if (r16 == 0) {
+                                f32x4 c4;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) cshift[e] = vr[e];
+                                for (int e = 0; e < 4; ++e) {
+                                    const unsigned wd = pw[2 * q + (e >> 1)];
+                                    c4[e] = ok ? __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16)) : 0.f;
+                                }
+                                *reinterpret_cast<f32x4*>(sh) = c4;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(sh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) cshift[4 * q + e] = c4[e];
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float d = vr[e] - cshift[e];
-                            f1[e] += d;
-                            f2[e] = fmaf(d, d, f2[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned wd = pw[2 * q + (e >> 1)];
+                            const float vr = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                            const float d = (vr - cshift[4 * q + e]) * live;
+                            f1[4 * q + e] += d;
+                            f2[4 * q + e] = fmaf(d, d, f2[4 * q + e]);
                         }
-                        ++nrow;
                     }
-                    *reinterpret_cast<uint4*>(y + off) = pk;
                 }
+                __builtin_amdgcn_sched_barrier(0);        // (the two halves one after the other: fewer live temporaries)
             }
+            if (want_stats && ok) ++nrow;
+            if (ok) *reinterpret_cast<uint4*>(y + ((size_t)m * K + k0)) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            __builtin_amdgcn_sched_barrier(0);            // one row at a time: interleaving both rows doubles the live temporaries
         }
     };
 
-    // =========================== the ping-pong loop ===========================
-    // phase k: group g runs X (MFMAs of its tile i = (k - g) / 2) when k + g is even, Y (epilogue of tile i = (k - g - 1) / 2,
-    // staging of tile i + 1) when it is odd.  Every wave passes exactly two barriers per phase.
-    __syncthreads();                                      // first operand images visible
-    PP_STAMP();
-    for (int k = 0; k < nint; ++k) {
-        const bool xrole = ((k + grp) & 1) == 0;
-        const int i = xrole ? (k - grp) >> 1 : (k - grp - 1) >> 1;
-        const bool on = i >= 0 && i < n_g && (k - grp) >= 0;
-        const int tile = t_beg + grp + 2 * i;
-        if (xrole) {
-            if (on) {
-                request(tile);
-                if (i + 1 < n_g) halo_load(tile + 2);     // in flight during both halves of X
-                tile_addr(tile);
+    // =========================== the tile loop ===========================
+    // Weight fragment of (tap, kk): row hc*32 + l31 of tile `tap`, 16-byte chunk (2 kk + hh) ^ sw(row); sw(l31 + 32) == sw(l31).
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        halo_store();                                     // BN+ReLU on the way into the operand image (waits for the tile's rows)
+        if (tile + 1 < t_end) halo_load(tile + 1);        // in flight during this tile's MFMAs and epilogue
+        if (res != nullptr || BWD) request(tile);
+        tile_addr(tile);
+        PP_STAMP();
+        __syncthreads();                                  // operand image complete
+        PP_STAMP();
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (hc < KH) {
+            const int l31f = pp_fresh(l31);
+            const unsigned char* wrow = sW + (hc * 32 + l31f) * (C * 2);
+            const int wsw = (l31f / RPB) & (CPR - 1);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
-                mma_steps(0, HALF);
+            for (int st = 0; st < RS * KS; ++st) {
+                const int tap = st / KS, kk = st - tap * KS;
+                const int r = tap / R, s = tap - r * R;
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sG + ab[r] + s * LDA + kk * 32 + hh * 16);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + tap * KP * (C * 2) + ((2 * kk + hh) ^ wsw) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
             }
-        } else if (on) {
-            epilogue(tile);
         }
         PP_STAMP();
-        __syncthreads();
+        __syncthreads();                                  // every wave is done reading the image: staging tiles may overwrite it
         PP_STAMP();
-        if (xrole) {
-            if (on) mma_steps(HALF, NSTEP);
-        } else if (on && i + 1 < n_g) {
-            halo_store();
-        }
+        epilogue(tile, tile == t_beg);
         PP_STAMP();
-        __syncthreads();
+        __syncthreads();                                  // staging tiles read back: the next operand image may overwrite them
         PP_STAMP();
     }
 
     // ---- statistics: one flush per block ----
+    // Each lane holds fp32 partial sums {sum (v - c), sum (v - c)^2} (forward: c = the wave's common shift of that channel;
+    // backward: {sum dz, sum dz * xhat}, c = 0) of 8 channels over its rows.  The 16 lanes of a channel chunk are combined by
+    // a transposition through the wave's own staging tile (48 LDS reads per lane; a shuffle tree is 77 dependent
+    // ds_bpermute round trips, 3 us at the end of every block), un-shifted once in fp64, then the waves of a channel half
+    // are added in a fixed order and ONE fp64 atomic pair per channel leaves the block.
     if (want_stats) {
-        double* s_red = reinterpret_cast<double*>(sW + RS * KP * C * 2);      // [8 waves][KP][2] (both regions are free now)
-        const int wave = tid >> 6;
-        const int cvl = lane % CVN;
-        float cs[8];
-        float nr = (float)nrow;
-        // shifted fp32 sums are re-based to a shift that is common to the lanes of a chunk (the first lane's), combined in
-        // fp32 across those lanes, and un-shifted once, in fp64 (same scheme as conv_epilogue_vec)
-        const float nfirst = __shfl(nr, cvl, 64);
+        float* rec = reinterpret_cast<float*>(sG + wave * (32 * LDST));      // [64 lanes][17]: f1[8] f2[8] nrow
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            cs[e] = (BWD || nfirst == 0.f) ? 0.f : __shfl(cshift[e], cvl, 64);
-            if (!BWD) {
-                const float d = cshift[e] - cs[e];
-                f2[e] = f2[e] + 2.f * d * f1[e] + nr * d * d;
-                f1[e] = f1[e] + nr * d;
-            }
+        for (int e = 0; e < 8; ++e) { rec[lane * 17 + e] = f1[e]; rec[lane * 17 + 8 + e] = f2[e]; }
+        rec[lane * 17 + 16] = (float)nrow;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int cv4 = (lane >> 3) & 3, ce = lane & 7;                     // lanes 0..31: channel 8 cv4 + ce of the wave's 32
+        float t1 = 0.f, t2 = 0.f, tn = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* src = rec + (r * 4 + cv4) * 17;
+            t1 += src[ce]; t2 += src[8 + ce]; tn += src[16];
         }
+        // common shift of this channel (every lane of the chunk holds the same one; lane cv4 is one of them)
+        float csv[8];
 #pragma unroll
-        for (int o = CVN; o < 64; o <<= 1) {
+        for (int e = 0; e < 8; ++e) csv[e] = BWD ? 0.f : cshift[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // all reads of `rec` done before it is reused
+        float* shf = rec;                                                    // [4 chunks][8]
+        if ((lane >> 2) == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f1[e] += __shfl_xor(f1[e], o, 64);
-                f2[e] += __shfl_xor(f2[e], o, 64);
-            }
-            nr += __shfl_xor(nr, o, 64);
+            for (int e = 0; e < 8; ++e) shf[(lane & 3) * 8 + e] = csv[e];
         }
-        if (lane < CVN) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const double c = (double)cs[e], n = (double)nr;
-                const double s1 = (double)f1[e] + n * c;
-                const double s2 = BWD ? (double)f2[e] : (double)f2[e] + 2.0 * c * (double)f1[e] + n * c * c;
-                s_red[(wave * KP + cvl * 8 + e) * 2 + 0] = s1;
-                s_red[(wave * KP + cvl * 8 + e) * 2 + 1] = s2;
-            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double c = (double)shf[cv4 * 8 + ce], n = (double)tn;
+        const double s1 = (double)t1 + n * c;
+        const double s2 = BWD ? (double)t2 : (double)t2 + 2.0 * c * (double)t1 + n * c * c;
+        __syncthreads();                                                     // every wave is done with its staging tile
+        double* s_red = reinterpret_cast<double*>(sG);                       // [8 waves][32][2]
+        if (lane < 32) {
+            s_red[(wave * 32 + lane) * 2 + 0] = s1;
+            s_red[(wave * 32 + lane) * 2 + 1] = s2;
         }
         __syncthreads();
         double* st = (BWD ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
         for (int t = tid; t < KP; t += 512) {
             if (n0 + t < K) {
+                const int h2 = t >> 5, c32 = t & 31;      // the PXW waves of channel half h2 hold partial sums of channel t
                 double u1 = 0.0, u2 = 0.0;
 #pragma unroll
-                for (int wv = 0; wv < 8; ++wv) { u1 += s_red[(wv * KP + t) * 2]; u2 += s_red[(wv * KP + t) * 2 + 1]; }
+                for (int q = 0; q < PXW; ++q) {
+                    u1 += s_red[((h2 * PXW + q) * 32 + c32) * 2];
+                    u2 += s_red[((h2 * PXW + q) * 32 + c32) * 2 + 1];
+                }
                 atomicAdd(st + n0 + t, u1);
                 atomicAdd(st + K + n0 + t, u2);
             }
@@ -448,12 +443,10 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
 #ifdef FPD_PP_TIMING
     PP_STAMP();
     __syncthreads();
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
-        // entry | tables+weights issued/stored | barrier | first image stored | barrier | per phase: half 1, barrier, half 2, barrier | flush
-        printf("conv_pp R=%d C=%d K=%d blk %d nt=%d nint=%d  g0:", R, C, K, (int)blockIdx.x, nt, nint);
-        for (int q = 1; q < 60 && s_stamp[q] != 0; ++q) printf(" %lld", s_stamp[q] - s_stamp[0]);
-        printf("\n   g1:");
-        for (int q = 0; q < 60 && s_stamp[60 + q] != 0; ++q) printf(" %lld", s_stamp[60 + q] - s_stamp[0]);
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 1)) {
+        // entry | tables+weights stored | barrier | per tile: staged+requests issued, barrier, MFMAs, barrier, epilogue, barrier | flush
+        printf("conv_pp R=%d C=%d K=%d blk %d tiles %d:", R, C, K, (int)blockIdx.x, t_end - t_beg);
+        for (int q = 1; q < 100 && s_stamp[q] != 0; ++q) printf(" %lld", s_stamp[q] - s_stamp[0]);
         printf("\n");
     }
 #endif
@@ -463,37 +456,54 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
 // hourglass level) in one launch.  A convolution owns nblk tile ranges x ks channel slabs = nblk * ks blocks ("units"); the
 // units of `b` are spread evenly over the grid (Bresenham), so that whatever subset of the grid is resident first serves both
 // in proportion.  gb.nblk == 0: single convolution.  Unit u -> (range, slab): the slabs of one range are 8 block ids apart,
-// i.e. on the same XCD (its L2 serves the operand rows to the second slab).
-template <int R, int C, int TN, bool BWD>
-__global__ __launch_bounds__(512, 2) void conv_pp_kernel(const fpd_conv_t a, const fpd_conv_t b, const PPGeo ga, const PPGeo gb,
-                                                         const int ks) {
-    const int bid = blockIdx.x, n = gridDim.x, nb = gb.nblk * ks;
+// i.e. on the same XCD.
+struct PPArgs { fpd_conv_t c[2]; PPGeo g[2]; int ks; };
+
+// Forward kernels fit 128 registers per lane (two blocks per CU); the BN-backward epilogue (epi_x prefetch, mask, two more sums)
+// does not without spilling the operand prefetch to scratch, so those kernels take the 256-register budget and one block per CU.
+template <int R, int C, int KH, bool BWD>
+__global__ __launch_bounds__(512, BWD ? 2 : 4) void conv_pp_kernel(const PPArgs p) {
+    const int bid = blockIdx.x, n = gridDim.x, ks = p.ks, nb = p.g[1].nblk * ks;
     const int fb0 = (int)((long long)bid * nb / n), fb1 = (int)((long long)(bid + 1) * nb / n);
-    const bool isb = fb1 > fb0;
+    const int isb = fb1 > fb0 ? 1 : 0;                    // (the descriptor is indexed, not branched on: ONE copy of the body)
     const int u = isb ? fb0 : bid - fb0;
-    const int nr = isb ? gb.nblk : ga.nblk;
+    const int nr = p.g[isb].nblk;
     int range, slab;
     if (ks == 2 && (nr & 7) == 0) { slab = (u >> 3) & 1; range = (u & 7) + 8 * (u >> 4); }
     else { slab = u % ks; range = u / ks; }
-    if (isb) conv_pp_body<R, C, TN, BWD>(b, gb, range, slab * 64);
-    else conv_pp_body<R, C, TN, BWD>(a, ga, range, slab * 64);
+    conv_pp_body<R, C, KH, BWD>(p.c[isb], p.g[isb], range, slab * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr size_t PP_LDS_MAX = 160 * 1024;
 
-// FPD_CONV_PP: 0 = never, 1 = launches with >= 512 tiles (default), 2 = whenever the shape is in the domain;
-// FPD_CONV_PP_BLOCKS: persistent grid (default: one block per compute unit).  Both can be changed at run time through
-// fpd_set_option("conv_pp" / "conv_pp_blocks", v) (tests drive small shapes through the kernel that way).
+// FPD_CONV_PP: 0 = never, 1 = launches with >= FPD_CONV_PP_MIN_TILES (256) pixel tiles (default), 2 = whenever the shape is in
+// the domain; FPD_CONV_PP_BLOCKS: persistent blocks per occupancy slot (default 128: the grid is that times the blocks a CU can
+// hold, at most 2 -- r03 sweep inside the pipelined step, one box: 64/96/128/256 x 2 -> 12.38/11.41/11.00/11.01 ms, 128/192/256 x 1
+// -> 11.35/11.12/11.03; threshold 512/256/128 tiles -> 11.00/10.79/10.78; conv_tile only: 11.50).  Both can be changed at run time through fpd_set_option("conv_pp" / "conv_pp_blocks", v)
+// (tests drive small shapes through the kernel that way).
 static int g_pp_mode = -1, g_pp_blocks = -1;
 static int pp_mode() {
-    if (g_pp_mode < 0) { const char* e = getenv("FPD_CONV_PP"); g_pp_mode = e ? atoi(e) : 0; }
+    if (g_pp_mode < 0) { const char* e = getenv("FPD_CONV_PP"); g_pp_mode = e ? atoi(e) : 1; }
     return g_pp_mode;
 }
 static int pp_blocks() {
-    if (g_pp_blocks < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS"); g_pp_blocks = e ? atoi(e) : 256; }
-    return g_pp_blocks < 2 ? 2 : g_pp_blocks;
+    if (g_pp_blocks < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS"); g_pp_blocks = e ? atoi(e) : 128; }
+    return g_pp_blocks < 1 ? 1 : g_pp_blocks;
 }
+static int pp_min_tiles() {  // FPD_CONV_PP_MIN_TILES: smallest launch (pixel tiles) the kernel takes in mode 1
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_MIN_TILES"); v = e ? atoi(e) : 256; }
+    return v;
+}
+static int pp_occ_cap() {    // FPD_CONV_PP_OCC: resident blocks per CU the grid is sized for (1 or 2)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_OCC"); v = e ? atoi(e) : 2; }
+    return v < 1 ? 1 : v;
+}
+
+static int pp_tile_px(const fpd_conv_t& a) { return a.K > 32 ? 128 : 256; }
+static int pp_nrows(const fpd_conv_t& a) { return std::max(1, pp_tile_px(a) / a.W); }
 
 static bool pp_domain(const fpd_conv_t& a) {
     if (a.dtype != FPD_BF16 || a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
@@ -501,48 +511,48 @@ static bool pp_domain(const fpd_conv_t& a) {
     if (a.C != 16 && a.C != 32 && a.C != 64 && a.C != 128) return false;
     if (a.K > 128 || a.K % 8 != 0) return false;
     if (a.R == 3 && a.C > 64) return false;                                // all nine weight tiles of a slab must fit the LDS
-    const int nrows = std::max(1, 128 / a.W);
-    if ((nrows + a.R - 1) * a.W * (a.C / 8) > 2048) return false;          // 8 operand vectors per thread
+    if ((pp_nrows(a) + a.R - 1) * a.W * (a.C / 8) > 2048) return false;    // 4 operand vectors per thread
     return true;
 }
-static int pp_tiles(const fpd_conv_t& a) { return cdiv(a.N * a.H, std::max(1, 128 / a.W)); }
+static int pp_tiles(const fpd_conv_t& a) { return cdiv(a.N * a.H, pp_nrows(a)); }
 
-template <int C, int TN>
+template <int C>
 static PPGeo pp_geo(const fpd_conv_t& a) {
-    constexpr int LDST = 32 * TN * 4 + 16, LDA = C * 2 + 16;
+    constexpr int LDST = 32 * 4 + 16, LDA = C * 2 + 16;
     PPGeo g;
-    g.nrows = std::max(1, 128 / a.W);
+    g.nrows = pp_nrows(a);
     g.ntiles = pp_tiles(a);
     g.nblk = 0;
     const int hrows = g.nrows + a.R - 1, WP = a.W + a.R - 1;
-    g.region = std::max((hrows * WP + 3) * LDA, 4 * 32 * LDST);
+    g.region = std::max((hrows * WP + 4) * LDA, 8 * 32 * LDST);
     g.mW = pp_magic(a.W);
     g.mWV = pp_magic(a.W * (C / 8));
     g.mH = pp_magic(a.H);
     return g;
 }
 
-template <int R, int C, int TN, bool BWD>
+template <int R, int C, int KH, bool BWD>
 static int pp_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
-    PPGeo ga = pp_geo<C, TN>(a), gb = ga;
+    PPGeo ga = pp_geo<C>(a), gb = ga;
     fpd_conv_t bb = a;
     gb.nblk = 0;
     int total = ga.ntiles;
     if (b != nullptr) {
-        gb = pp_geo<C, TN>(*b);
+        gb = pp_geo<C>(*b);
         bb = *b;
         total += gb.ntiles;
     }
     const int region = std::max(ga.region, b ? gb.region : 0);
     ga.region = gb.region = region;
-    size_t lds = (size_t)(2 * C + 5 * 32 * TN) * sizeof(float) + (size_t)R * R * 32 * TN * C * 2 + 2 * (size_t)region;
+    size_t lds = (size_t)(2 * C + 5 * 32 * KH) * sizeof(float) + (size_t)R * R * 32 * KH * C * 2 + (size_t)region;
 #ifdef FPD_PP_TIMING
     lds += 1024;
 #endif
     if (lds > PP_LDS_MAX) return 1;
+    const int occ = BWD ? 1 : std::max(1, std::min(pp_occ_cap(), (int)(PP_LDS_MAX / lds)));
     const int ks = cdiv(a.K, 64);                          // channel slabs of <= 64 (K = 128: two blocks per tile range)
-    // tile ranges: every block should own at least two tiles (one per group); ks blocks per range
-    int ranges = std::max(1, std::min(pp_blocks() / ks, total / 2));
+    // tile ranges: ks blocks per range, every block should own at least two tiles
+    int ranges = std::max(1, std::min(pp_blocks() * occ / ks, total / 2));
     if (b != nullptr) {
         if (ranges < 2) return 1;
         gb.nblk = std::max(1, std::min(ranges - 1, (int)((long long)ranges * gb.ntiles / total)));
@@ -553,12 +563,14 @@ static int pp_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st)
     const int grid = (ga.nblk + gb.nblk) * ks;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, TN, BWD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, KH, BWD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
-    hipLaunchKernelGGL((conv_pp_kernel<R, C, TN, BWD>), dim3(grid), dim3(512), lds, st, a, bb, ga, gb, ks);
+    PPArgs args;
+    args.c[0] = a; args.c[1] = bb; args.g[0] = ga; args.g[1] = gb; args.ks = ks;
+    hipLaunchKernelGGL((conv_pp_kernel<R, C, KH, BWD>), dim3(grid), dim3(512), lds, st, args);
     return 0;
 }
 
@@ -596,7 +608,7 @@ int fpd_conv_pp_option(int which, int value) {     // which: 0 = mode, 1 = block
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st) {
     const int mode = pp_mode();
     if (mode == 0 || !pp_domain(a)) return 1;
-    if (mode == 1 && pp_tiles(a) < 512) return 1;
+    if (mode == 1 && pp_tiles(a) < pp_min_tiles()) return 1;
     return pp_launch(a, nullptr, st);
 }
 
@@ -605,6 +617,6 @@ int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_
     const int mode = pp_mode();
     if (mode == 0 || !pp_domain(a) || !pp_domain(b)) return 1;
     if (a.K != b.K || a.C != b.C || a.R != b.R || a.epi != b.epi) return 1;
-    if (mode == 1 && pp_tiles(a) + pp_tiles(b) < 512) return 1;
+    if (mode == 1 && pp_tiles(a) + pp_tiles(b) < pp_min_tiles()) return 1;
     return pp_launch(a, &b, st);
 }

@@ -2,7 +2,7 @@
 # round-3 probe 1: what each class of ops costs INSIDE the pipelined step (FPD_WHATIF lowers the class to no-ops: timing only,
 # results are wrong), base and variants interleaved on ONE box.  Output: gpurun_out/r03whatif/summary.txt
 cd "$(dirname "$0")/../.." || exit 1
-O=gpurun_out/r03whatif; mkdir -p $O
+O=gpurun_out/${WHATIF_OUT:-r03whatif}; mkdir -p $O
 run() {  # name, FPD_WHATIF value, extra env
   FPD_WHATIF="$2" timeout 200 env $3 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $O/$1.json 2> $O/$1.err
   python -c "import json;d=json.load(open('$O/$1.json'));print('%-28s %7.3f ms/step' % ('$1', d['ms_per_step']))" 2>/dev/null || { echo "$1 FAILED"; tail -3 $O/$1.err; }
