@@ -61,10 +61,11 @@ def _cpu_time(pair, batch, steps, no_grad, seed=0):
 
 
 def cpu_baseline():
-    """the oracle on the GPU box's host cores, bounded to ~40 s of CPU work.  Thread count swept on
-    cfg-1 (one timed step each), then the best count times cfg-1 (B=2, 3 steps) and the benchmark pair (B=4, 2 steps), each
-    with the teacher under no_grad and reference-faithful (teacher graph retained, function.py:120).  `value` = images/s
-    of the benchmark pair with the teacher under no_grad (the faster variant: the stronger baseline)."""
+    """the oracle on the GPU box's host cores.  Thread count swept on cfg-1 (one timed step each), then
+    the best count times cfg-1 (hg2x64, B=2) and the benchmark pair (hg4x128 <- hg8x256, B=8) with 3 timed steps after one
+    warm-up each, both with the teacher under no_grad and reference-faithful (teacher graph retained, function.py:120; if the
+    budget of ~90 s is exhausted the faithful B=8 variant falls back to fewer steps and says so).  `value` = images/s of
+    the benchmark pair with the teacher under no_grad (the faster variant: the stronger baseline)."""
     ncpu = os.cpu_count() or 1
     cfg1, pair = ((64, 2), (64, 2)), ((128, 4), (256, 8))
     t_begin = time.time()
@@ -85,12 +86,14 @@ def cpu_baseline():
         return batch / dt
     run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, True)
     run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, False)
-    big_b = 4
-    v = run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 2, True)
-    if time.time() - t_begin < 60:
-        run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 1, False)
+    big_b = 8
+    v = run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 3, True)
+    left = 90 - (time.time() - t_begin)
+    per = variants[-1]['s_per_step'] * 2.0                               # the retained teacher graph costs about 2x
+    steps_f = 3 if per * 4 < left else max(1, int(left / per) - 1)
+    run('cfg-2 hg4x128 <- hg8x256', pair, big_b, steps_f, False)
     return {'value': round(v, 3), 'unit': 'images/s', 'cores': best, 'kind': 'port',
-            'sample': 'same FPD pair (hg4x128 <- hg8x256, 256x256) at batch %d, 2 timed steps after 1 warm-up, torch CPU fp32 '
+            'sample': 'same FPD pair (hg4x128 <- hg8x256, 256x256) at batch %d, 3 timed steps after 1 warm-up, torch CPU fp32 '
                       'oracle, teacher under no_grad, %d threads (best of the sweep on %d host CPUs)' % (big_b, best, ncpu),
             'thread_sweep_cfg1_images_per_s': sweep, 'variants': variants}
 
@@ -103,6 +106,8 @@ def dominant_kernel(step, R, launches=50):
     if not ops:
         return None
     op = ops[0]
+    n_single = sum(1 for o in t.g.fwd if o.kind == 'bneck' and o.dims[1] == 64)
+    n_paired = sum(1 for o in t.g.fwd if o.kind == 'bneck2' and (o.a.dims[1] == 64 or o.b.dims[1] == 64))
     n, h, w, c, p = op.dims
     plan = R.Plan()
     plan.add(*t.low.op(op))
@@ -118,7 +123,8 @@ def dominant_kernel(step, R, launches=50):
     us = l.fpd_event_elapsed_ms(e0, e1) / launches * 1e3
     flops = 2.0 * n * h * w * (c * p + 9 * p * p + p * c)
     return {'name': 'bneck_eval_kernel<128> N=%d %dx%d C=%d P=%d (teacher Bottleneck, conv1x1+conv3x3+conv1x1 fused)' % (n, h, w, c, p),
-            'us': us, 'flops': flops, 'bytes_algorithmic': 2.0 * n * h * w * c * 2, 'launches': launches}
+            'us': us, 'flops': flops, 'bytes_algorithmic': 2.0 * n * h * w * c * 2, 'launches': launches,
+            'per_step': (n_single, n_paired), 'grid_cap': int(os.environ.get('FPD_BNECK_BLOCKS', '128'))}
 
 
 def parity_object(hourglass, E, synth, student, teacher, batch, dev, J, H, W):
@@ -324,6 +330,7 @@ def main():
     l.fpd_event_record(ev0, st)
     step.run_pipelined(args.steps, allreduce)      # K teacher forwards + K student steps, pipeline starts/ends empty
     l.fpd_event_record(ev1, st)
+    host_enqueue_ms = (time.time() - t0) / args.steps * 1e3      # nothing in there synchronises: pure launch-path time
     barrier()
     wall = time.time() - t0
     ev_ms = l.fpd_event_elapsed_ms(ev0, ev1)
@@ -344,22 +351,29 @@ def main():
                                                                                               ev_ms / args.steps)}
     dom = dominant_kernel(step, R) if (rank == 0 and args.dtype == 'bf16' and not hr) else None
     if dom is not None:
-        traffic = None
-        for name in ('r02_pmc_bneck64.json', 'r01_pmc_bneck64.json'):      # HBM bytes/launch from separate --pmc passes
+        # HBM bytes/launch from separate rocprofv3 --pmc passes (tools/pmc_bneck.sh), only if that file was measured at the
+        # launch geometry timed here (grid cap): a file from another geometry is refused, not quoted
+        traffic, traffic_note = None, 'no PMC file under profiles/'
+        for name in ('r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-                break
+                d = json.load(open(pmc))
+                if d.get('grid_cap') == dom['grid_cap']:
+                    traffic, traffic_note = d.get('hbm_bytes_per_launch'), 'profiles/%s (grid cap %d)' % (name, dom['grid_cap'])
+                    break
+                traffic_note = 'profiles/%s was measured at grid cap %s, this run uses %d: not quoted' % (name, d.get('grid_cap', 'unknown (r02: 147-160)'), dom['grid_cap'])
         k_ach = dom['flops'] / (dom['us'] * 1e-6) / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(k_ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(k_ach / peak, 4), 'traffic': traffic, 'kernel': dom['name'],
                     'avg_us': round(dom['us'], 2), 'flop_per_launch': dom['flops'],
                     'algorithmic_bytes_per_launch': dom['bytes_algorithmic'],
-                    'note': 'dominant (kernel, shape) of the step: 17 launches/step, timed AS LAUNCHED IN THE STEP (persistent grid capped at '
-                            'FPD_BNECK_BLOCKS=128 of 256 CUs so that the concurrent student chain finds free compute units; uncapped the '
+                    'launches_per_step': {'single': dom['per_step'][0], 'paired_with_a_32x32_one': dom['per_step'][1]},
+                    'grid_cap': dom['grid_cap'], 'traffic_source': traffic_note,
+                    'note': 'dominant (kernel, shape) of the step, timed AS LAUNCHED IN THE STEP (persistent grid capped at '
+                            'FPD_BNECK_BLOCKS of 256 CUs so that the concurrent student chain finds free compute units; uncapped the '
                             'same kernel runs ~100 us = 0.22 of peak, DESIGN.md section 5); %d back-to-back launches timed with HIP '
-                            'events on the launch stream after the timed region; traffic = HBM bytes/launch from the committed '
-                            'rocprofv3 --pmc passes (profiles/), null if absent' % dom['launches'],
+                            'events on the launch stream after the timed region; traffic = HBM bytes/launch from rocprofv3 --pmc '
+                            'passes at the same grid cap (profiles/), null if absent' % dom['launches'],
                     'step': step_roof}
     else:
         roofline = {'bound': 'mfma', 'achieved': step_roof['achieved'], 'peak': peak, 'unit': 'TFLOP/s',
@@ -380,9 +394,18 @@ def main():
                                'fused FPD step incl. Adam, teacher forward one batch ahead on a 2nd stream%s' % (' + RCCL all-reduce' if use_dist else ''),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,
                    'launch': 'hipGraph replay per phase' if args.graphs else 'one native plan call per phase, kernels launched eagerly on 3 streams',
+                   'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+                   'launches_per_step': step.launches_per_step(),
+                   'ranks': world,
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
         'roofline': roofline,
     }
+    if use_dist:
+        out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        exp = getattr(allreduce, 'exposed_us', None)
+        out['config']['allreduce_exposed_us'] = round(exp(), 1) if exp else None
+        out['config']['allreduce'] = 'one asynchronous RCCL all-reduce per gradient bucket (%d buckets, %d fp32 elements in total), waited for before Adam' % (
+            len(student.table.buckets), student.table.sizes['param'])
     if rank == 0:
         print('[bench] timed region done: %.3f ms/step; parity / cpu baseline next' % ms_per_step, file=sys.stderr, flush=True)
     if init_sd is not None:

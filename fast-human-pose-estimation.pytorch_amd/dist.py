@@ -20,11 +20,32 @@ def make_allreduce(dist, group=None):
     of the backward is still executing; only the last bucket's is exposed, and even that overlaps the next step's
     teacher forward (the student stream waits for the collectives right before Adam)."""
     comm = {}
+    spans = []                          # (event before, event after) around the student stream's waits: exposed collective time
+
+    def timed(wait):
+        def w():
+            if not torch.cuda.is_available():
+                return wait()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            wait()
+            e1.record()
+            spans.append((e0, e1))
+            if len(spans) > 256:
+                del spans[:128]
+        return w
+
+    def exposed_us():
+        """Mean time per step the consuming stream sat in front of Adam waiting for the collectives (synchronises)."""
+        if not spans:
+            return 0.0
+        torch.cuda.synchronize()
+        return 1e3 * sum(a.elapsed_time(b) for a, b in spans) / len(spans)
 
     def hook(flat_grad, buckets=None):
         if not buckets or not flat_grad.is_cuda:
             work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
-            return work.wait            # makes the current stream wait for the collective; no host sync on NCCL/RCCL
+            return timed(work.wait) if flat_grad.is_cuda else work.wait     # current stream waits for the collective; no host sync on RCCL
         if 's' not in comm:
             comm['s'] = torch.cuda.Stream(device=flat_grad.device)
         works = []
@@ -42,7 +63,8 @@ def make_allreduce(dist, group=None):
                 w.wait()                # current stream waits for each collective (device-side)
             return None
         del cur
-        return wait_all
+        return timed(wait_all)
+    hook.exposed_us = exposed_us
     return hook
 
 

@@ -735,6 +735,17 @@ class FusedFPDStep:
             self._dist_work = None
             self.student.run('adam')
 
+    def launches_per_step(self):
+        """Plan ops (= kernel launches / memsets; no-ops excluded) one iteration enqueues, per phase."""
+        def count(inst, name):
+            b, e = inst.rng[name]
+            return sum(1 for k in range(b, e) if inst.plan.op_type(k) != R.OP_NOP)
+        out = {'teacher_fwd': count(self.teacher, 'fwd') * len(self.teachers)} if self.teacher is not None else {}
+        for ph in ('prep', 'fwd', 'mid', 'bwd', 'adam'):
+            out['student_' + ph] = count(self.student, ph)
+        out['total'] = sum(out.values())
+        return out
+
     def losses(self):
         """(pose, kd, total) of the last step -- synchronises."""
         l = self.student.A.tensor('losses')[:2].cpu()

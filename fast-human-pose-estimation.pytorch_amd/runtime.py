@@ -291,12 +291,17 @@ class Plan:
         self._l = lib()
         self._p = C.c_void_p(self._l.fpd_plan_create())
         self._graphs = {}
+        self._types = []                 # op code of every plan op (host-side bookkeeping: launches per phase)
 
     def add(self, op, args):
         rc = self._l.fpd_plan_add(self._p, op, C.byref(args), C.sizeof(args))
         if rc < 0:
             check(rc, 'fpd_plan_add')
+        self._types.append(op)
         return rc
+
+    def op_type(self, k):
+        return self._types[k]
 
     def __len__(self):
         return self._l.fpd_plan_size(self._p)

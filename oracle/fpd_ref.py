@@ -159,6 +159,33 @@ def synth_batch(seed, batch, num_joints, image_size=(256, 256), heatmap_size=(64
     return torch.from_numpy(inp), torch.from_numpy(tg), torch.from_numpy(tw)
 
 
+def blob_batch(seed, batch, num_joints, image_size=(256, 256), heatmap_size=(64, 64), sigma=2, p_vis=0.85, noise=0.3):
+    """Seeded synthetic batch with LEARNABLE structure (the random crops of synth_batch carry no information about their
+    joints, so a network trained on them can only learn the mean map): every visible joint is drawn into the image as a
+    Gaussian blob of 4*sigma pixels in a joint-specific colour (16 colours: 8 hues x 2 signs of the third channel), on
+    weak noise.  Targets / weights exactly as synth_batch (JointsDataset.generate_target).  Used by the trained-pair
+    fixture (tests/golden/make_golden_trained.py) and the convergence test."""
+    rng = np.random.RandomState(seed)
+    w, h = image_size
+    inp = (noise * rng.standard_normal((batch, 3, h, w))).astype(np.float32)
+    tg = np.zeros((batch, num_joints, heatmap_size[1], heatmap_size[0]), np.float32)
+    tw = np.zeros((batch, num_joints, 1), np.float32)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    s_img = 4.0 * sigma
+    for b in range(batch):
+        xy = np.stack([rng.uniform(0.1 * w, 0.9 * w, num_joints), rng.uniform(0.1 * h, 0.9 * h, num_joints)], 1)
+        vis = (rng.uniform(0, 1, num_joints) < p_vis).astype(np.float32)
+        tg[b], tw[b] = generate_target(xy, vis, image_size, heatmap_size, sigma)
+        for j in range(num_joints):
+            if tw[b, j, 0] < 0.5:
+                continue
+            th = 2.0 * np.pi * (j % 8) / 8.0
+            col = np.array([np.cos(th), np.sin(th), 1.0 if j < 8 else -1.0], np.float32) * 2.0
+            g = np.exp(-((xs - xy[j, 0]) ** 2 + (ys - xy[j, 1]) ** 2) / (2.0 * s_img ** 2))
+            inp[b] += col[:, None, None] * g[None]
+    return torch.from_numpy(inp), torch.from_numpy(tg), torch.from_numpy(tw)
+
+
 def synth_state_dict(keys, seed):
     """Deterministic synthetic checkpoint for a list of (key, shape): conv weights/biases
     uniform(+-1/sqrt(fan_in)) (the scale of torch's default init), BN affine near (1, 0) with

@@ -9,8 +9,9 @@ initialisation is.  Pre-training on the device made the tr
 script produces ONE committed pair instead: `/root/reference/lib/models/hourglass.py` HourglassNet (student hg2x32, teacher
 hg3x64, the 'tiny' shapes of tests/_cases.py) + `/root/reference/lib/core/loss.py` JointsMSELoss + torch.optim.Adam
 (lib/utils/utils.py:69-73), plain supervised training (the loop body of lib/core/function.py:28-96: per-stack loss sum,
-zero_grad / backward / step) for STEPS iterations on the seeded synthetic batches of oracle.fpd_ref.synth_batch, fp32 on the
-CPU.  Stored: both state_dicts (fp32, BN running statistics included) and the loss curves.
+zero_grad / backward / step) for STEPS iterations on the seeded, LEARNABLE synthetic batches of oracle.fpd_ref.blob_batch
+(colour-coded joint blobs: the random crops of synth_batch carry no information about their joints), fp32 on the CPU.
+Stored: both state_dicts (fp32, BN running statistics included) and the loss curves.
 """
 import importlib.util
 import os
@@ -27,7 +28,7 @@ REF = '/root/reference'
 from oracle import fpd_ref, hourglass_ref  # noqa: E402
 from tests._cases import CONFIGS  # noqa: E402
 
-STEPS = 300
+STEPS = 500
 LR = 1e-3
 
 
@@ -56,7 +57,7 @@ def train(ref_hg, ref_loss, c, feats, stacks, seed, seed0):
     net.train()
     curve = []
     for it in range(STEPS):
-        x, g, w = fpd_ref.synth_batch(seed0 + it, c['batch'], c['joints'], c['image'], c['heat'])
+        x, g, w = fpd_ref.blob_batch(seed0 + it, c['batch'], c['joints'], c['image'], c['heat'])
         outputs = net(x)                              # lib/core/function.py:47-60: sum of the per-stack losses
         loss = crit(outputs[0], g, w)
         for o in outputs[1:]:

@@ -81,6 +81,10 @@ def product_step(student, teacher, x, tg, tw, tmap_fixed, B, H, W):
     return ours_tmap, maps, step.losses(), grads
 
 
+TRAINED_MAP_CEILING = 0.15       # trained pair, deterministic fixture: maps <= 0.15, gradients <= 0.5
+TRAINED_GRAD_CEILING = 0.5
+
+
 def check(label, ours, ref_bf16, floor, ceiling, slack=1.5):
     print('%-34s ours %.3e   reference@bf16 %.3e   (floor %.1e, ceiling %.1e)' % (label, ours, ref_bf16, floor, ceiling))
     assert ours <= max(floor, slack * ref_bf16), (label, 'less accurate than %.1fx the reference at bf16' % slack, ours, ref_bf16)
@@ -152,43 +156,38 @@ def test_tiny_bf16_20_step_trajectory_vs_reference_at_bf16():
     assert ours[-1, 2] < ours[0, 2] and t64[-1, 2] < t64[0, 2], (ours[:, 2], t64[:, 2])
 
 
-def _pretrain(model, name, steps, seed0, lr=1e-3):
-    """Plain (non-distillation) fp32 training of `model` on synthetic targets through the product's fused step."""
-    from fpd_amd import executor as E
-    c = _cases.CONFIGS[name]
-    B, (W, H) = c['batch'], c['image']
-    step = E.FusedFPDStep(model.device_state(), model.cfg_hg, None, None, B, H, W, alpha=0.0, lr=lr)
-    for it in range(steps):
-        x, tg, tw = fpd_ref.synth_batch(seed0 + it, B, c['joints'], c['image'], c['heat'])
-        step.set_batch(x, tg, tw)
-        step.step()
-    torch.cuda.synchronize()
-    return step.losses()[0]
+def trained_state_dicts():
+    """The 'tiny' student / teacher pair TRAINED by the reference's own modules (tests/golden/make_golden_trained.py:
+    300 Adam steps each on CPU, fp32) -- a committed fixture, identical on every run."""
+    import os
+    z = np.load(os.path.join(_cases.GOLDEN, 'trained_tiny.npz'))
+    out = []
+    for tag in ('s', 't'):
+        sd = {}
+        for k in z.files:
+            if k.startswith(tag + '/'):
+                v = torch.from_numpy(z[k].copy())
+                sd[k[2:]] = v
+        out.append(sd)
+    return out
 
 
 def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
-    """Separates kernel error from network chaos: student and teacher of the 'tiny' pair are first
-    TRAINED (250 plain fp32 Adam steps each on synthetic targets, through the product's own fp32 step), then one FPD
-    iteration and a 20-step trajectory are evaluated in the bf16 build against the fp64 oracle: absolute bounds, and
-    never worse than 1.5x the reference at bf16."""
-    from fpd_amd import executor as E
+    """Separates kernel error from network chaos: student and teacher of the 'tiny' pair are TRAINED networks (committed
+    checkpoints produced by the reference's own modules + torch Adam, tests/golden/make_golden_trained.py), so every figure
+    below is deterministic.  One FPD iteration is evaluated in the bf16 build against the fp64 oracle: absolute bounds, and
+    never worse than 1.5x the reference at bf16 (the oracle under bf16 autocast)."""
     from fpd_amd.lib.models import hourglass
-    from tests.test_model_gpu import build_models
     name = 'tiny'
-    c, gold, s32, t32 = build_models(name, 'fp32')
-    t32.train()
-    l_t = _pretrain(t32, name, 250, 5000)
-    l_s = _pretrain(s32, name, 250, 7000)
-    print('pre-training: teacher loss %.4f, student loss %.4f' % (l_t, l_s))
-    s_sd = {k: v.detach().cpu().clone() for k, v in s32.state_dict().items()}
-    t_sd = {k: v.detach().cpu().clone() for k, v in t32.state_dict().items()}
+    c = _cases.CONFIGS[name]
+    s_sd, t_sd = trained_state_dicts()
     student = hourglass.get_pose_net(_cfg(c['s'][0], c['s'][1], c['joints'], 'bf16'), is_train=True)
     teacher = hourglass.get_pose_net(_cfg(c['t'][0], c['t'][1], c['joints'], 'bf16'), is_train=False)
     student.load_state_dict(s_sd, strict=True)
     teacher.load_state_dict(t_sd, strict=True)
     student, teacher = student.cuda(), teacher.cuda()
     B, (W, H) = c['batch'], c['image']
-    x, tg, tw = _cases.batch(name, 0)
+    x, tg, tw = fpd_ref.blob_batch(100, B, c['joints'], c['image'], c['heat'])      # a batch of the distribution the pair was trained on
     t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
     with torch.no_grad():
         tr_tmap = hourglass_ref.hourglass_forward(t64, x.double(), c['t'][1], train=False)[-1]
@@ -199,15 +198,143 @@ def test_trained_pair_bf16_vs_fp64_absolute_and_vs_reference_at_bf16():
     s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
     t_maps, t_loss, t_grads = student_step(s64, x.double(), tg.double(), tw.double(), tmap_fixed.double(), c['s'][1])
     a_maps, a_loss, a_grads = student_step({k: v.clone() for k, v in s_sd.items()}, x, tg, tw, tmap_fixed, c['s'][1], autocast='cpu')
-    # the pre-training above runs on the device (fp32 atomics in the weight gradients: reproducible to rounding only), so the
-    # trained pair -- and with it both error figures -- differs from run to run; over six runs ours ranged 0.094 .. 0.21 and the
-    # reference at bf16 0.084 .. 0.20 on their own, their ratio 0.63 .. 2.04: a ratio of two noisy realisations, hence slack 3.0
-    # here; the 0.3 ceiling (a broken kernel gives O(1)) and the per-kernel / golden tests are the sharp checks
-    check('trained teacher map rel-L2', rel(ours_tmap, tr_tmap), rel(a_tmap, tr_tmap), 2e-2, 0.3, slack=3.0)
+    check('trained teacher map rel-L2', rel(ours_tmap, tr_tmap), rel(a_tmap, tr_tmap), 2e-2, TRAINED_MAP_CEILING)
     for i in range(len(maps)):
-        check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, 0.35)
+        check('trained student map %d rel-L2' % i, rel(maps[i], t_maps[i]), rel(a_maps[i], t_maps[i]), 2e-2, TRAINED_MAP_CEILING)
     for nm, o, a, t in zip(('pose', 'kd', 'total'), losses, a_loss, t_loss):
-        # single-step losses of the trained pair: ours ranged 2e-4 .. 1.3e-2 and the reference at bf16 2e-6 .. 1.9e-2 over nine
-        # runs (different trained pairs, see above) -- a floor of 2e-2 under the 3e-2 ceiling keeps the check out of that noise
-        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 2e-2, 3e-2)
-    check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, 1.3)
+        check('trained %s loss rel err' % nm, abs(o - t) / abs(t), abs(a - t) / abs(t), 1e-2, 3e-2)
+    check('trained gradient rel-L2', grads_rel(grads, t_grads), grads_rel(a_grads, t_grads), 5e-2, TRAINED_GRAD_CEILING)
+
+
+# ---- kernel error separated from network chaos: one Bottleneck at a time, identical inputs, fp64 referee ---------------
+def _bneck_chain(L, N, H, W, C, backend):
+    """A chain of L train-mode pre-activation Bottlenecks (hourglass.py:32-52) as the product's own op list on bf16 storage
+    (csrc conv kernels through the C ABI), beside (i) the bf16 specification (oracle/plan_interp, same rounding points) and
+    (ii) an fp64 evaluation of the same graph on the SAME bf16-representable input and weights, with no rounding anywhere.
+    Returns [(|gpu - fp64|, |spec - fp64|) relative L2] after Bottleneck 1..L."""
+    import torch.nn.functional as F
+    from tests import test_kernels_gpu as TK
+    TK.setup_module(TK)
+    G = TK.G
+    P = C // 2
+    gen = torch.Generator().manual_seed(1234 + L + H)
+    bt = TK.Bench(1)
+    M = N * H * W
+    x_val = (TK.rnd(gen, N, H, W, C) + 0.3).to(torch.bfloat16).float()
+    x = bt.act((N, H, W, C), x_val, 'x0')
+    stats = bt.buf('stats', (TK.RS, 2, C), TK.tensor_stats(x_val))
+    ops, layers, outs = [], [], []
+    cur, cur_stats = x, stats
+    for l in range(L):
+        lay = {}
+        for nm, (k, r, c) in (('1', (P, 1, C)), ('2', (P, 3, P)), ('3', (C, 1, P))):
+            wv = (TK.rnd(gen, k, r, r, c) / np.sqrt(c * r * r)).to(torch.bfloat16).float()
+            lay['w' + nm] = (bt.buf('wlp', (k, r, r, c), wv), wv)
+            bv = 0.1 * TK.rnd(gen, k)
+            lay['b' + nm] = (bt.buf('param', (k,), bv), bv)
+            g_, b_ = 1 + 0.2 * TK.rnd(gen, c), 0.2 * TK.rnd(gen, c)
+            bn = G.BN('bn%d_%s' % (l, nm), 'train', c, bt.buf('param', (c,), g_), bt.buf('param', (c,), b_),
+                      bt.buf('rstat', (c,), torch.zeros(c)), bt.buf('rstat', (c,), torch.ones(c)), bt.buf('nbt', ()), relu=True)
+            bn.count = M
+            lay['bn' + nm] = (bn, g_, b_)
+        layers.append(lay)
+
+        def conv(xa, nm, k, r, c, res, xs):
+            bn = lay['bn' + nm][0]
+            bn.stats = xs
+            y = bt.act((N, H, W, k), None, 'y%d_%s' % (l, nm))
+            st = bt.buf('stats', (TK.RS, 2, k), torch.zeros(TK.RS, 2, k, dtype=torch.float64))
+            ops.append(G.Op('conv', x=xa, w=lay['w' + nm][0], wkey='w', bias=lay['b' + nm][0], bkey='b', residual=res, y=y, out_stats=st,
+                            bn=bn, epi='plain', epi_x=None, epi_bn=None, epi_stats=None,
+                            dims=(N, H, W, c, k, r, r, 1, (r - 1) // 2, H, W)))
+            return y, st
+        t1, s1 = conv(cur, '1', P, 1, C, None, cur_stats)
+        t2, s2 = conv(t1, '2', P, 3, P, None, s1)
+        cur, cur_stats = conv(t2, '3', C, 1, P, cur, s2)
+        outs.append(cur)
+    bt.realise().run(ops, backend)
+
+    # fp64 referee: same graph, no rounding
+    def bnrelu(t, g_, b_):
+        m = t.mean((0, 1, 2))
+        v = ((t - m) ** 2).mean((0, 1, 2))
+        return torch.clamp_min((t - m) / torch.sqrt(v + 1e-5) * g_.double() + b_.double(), 0)
+
+    def cv(t, wv, bv, r):
+        return F.conv2d(t.permute(0, 3, 1, 2), wv.double().permute(0, 3, 1, 2), bv.double(), padding=(r - 1) // 2).permute(0, 2, 3, 1)
+    t = x_val.double()
+    res = []
+    for l, lay in enumerate(layers):
+        a = cv(bnrelu(t, *lay['bn1'][1:]), lay['w1'][1], lay['b1'][1], 1)
+        a = cv(bnrelu(a, *lay['bn2'][1:]), lay['w2'][1], lay['b2'][1], 3)
+        t = t + cv(bnrelu(a, *lay['bn3'][1:]), lay['w3'][1], lay['b3'][1], 1)
+        gpu = bt.gpu.view(outs[l].buf).double().cpu()
+        spec = bt.cpu.view(outs[l].buf).double()
+        res.append((float((gpu - t).norm() / t.norm()), float((spec - t).norm() / t.norm())))
+    return res
+
+
+@pytest.mark.parametrize('backend,shape', [(0, (8, 32, 32, 128)), (('pp', 16), (8, 32, 32, 128)), (('pp', 64), (2, 64, 64, 128)), (0, (32, 8, 8, 128))])
+def test_bottleneck_chain_error_growth_bf16(backend, shape):
+    """Per-Bottleneck error of the bf16 kernels (VERDICT r2 #3c): identical bf16-representable input and weights, fp64
+    referee, NO network-level amplification argument.  A Bottleneck rounds seven tensors to bf16 (three BN+ReLU'd operands,
+    three convolution outputs incl. the block output): with unit roundoff u = 2^-9 and errors adding in quadrature the
+    relative L2 error after L blocks is ~ u * sqrt(7 L) * O(1).  Required: (a) <= 1.25 u sqrt(7 L) absolutely -- MEASURED
+    0.60 .. 0.71 of u sqrt(7 L) (3.1e-3 after one block, 7.0 .. 7.3e-3 after four, r03 on the MI355X); (b) within 1.25x of the bf16 SPECIFICATION's own error (oracle/plan_interp: same rounding
+    points, torch fp32 arithmetic): the kernels add nothing beyond the storage format."""
+    L = 4
+    N, H, W, C = shape
+    u = 2.0 ** -9
+    res = _bneck_chain(L, N, H, W, C, backend)
+    for l, (g, sp) in enumerate(res, 1):
+        bound = 1.25 * u * (7 * l) ** 0.5
+        print('backend %r %r: after %d Bottleneck(s): |kernels - fp64| %.3e   |bf16 spec - fp64| %.3e   bound %.3e' % (backend, shape, l, g, sp, bound))
+        assert g <= bound, (l, g, bound)
+        assert g <= 1.25 * sp + 1e-4, (l, g, sp)
+
+
+def test_bf16_training_converges_like_fp32():
+    """VERDICT r2 #3d: STEPS (>= 200) FPD steps on a fixed, learnable synthetic set (16 colour-coded-blob batches, cycled) from
+    the same initial student, against the same frozen TRAINED teacher (committed fixture), once in the bf16 build and once in
+    the fp32 parity build; then one more pass over the 16 batches with lr = 0 as the evaluation (train-mode forward: per-batch
+    BN statistics, the metric of function.py:154-155).  The bf16 run must end where the fp32 run ends: total loss within 5 %,
+    PCK@0.5 of the last student map (device metric, ~430 visible joints) within 0.02 -- and both must actually have learned."""
+    from fpd_amd import executor as E
+    from fpd_amd.lib.models import hourglass
+    STEPS = 600
+    name = 'tiny'
+    c = _cases.CONFIGS[name]
+    _, t_sd = trained_state_dicts()
+    B, (W, H) = c['batch'], c['image']
+    batches = [fpd_ref.blob_batch(9000 + i, B, c['joints'], c['image'], c['heat']) for i in range(16)]
+    s0 = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(c['s'][0], c['s'][1], c['joints']), 1)
+    out = {}
+    for dt in ('fp32', 'bf16'):
+        student = hourglass.get_pose_net(_cfg(c['s'][0], c['s'][1], c['joints'], dt), is_train=True)
+        teacher = hourglass.get_pose_net(_cfg(c['t'][0], c['t'][1], c['joints'], dt), is_train=False)
+        student.load_state_dict({k: v.clone() for k, v in s0.items()}, strict=True)
+        teacher.load_state_dict(t_sd, strict=True)
+        student, teacher = student.cuda(), teacher.cuda()
+        step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5, lr=1e-3)
+        metric = step.enable_metric()
+        for it in range(STEPS):
+            step.set_batch(*batches[it % 16])
+            step.step()
+        first = metric.drain(full=True)
+        step.set_lr(0.0)
+        for it in range(16):
+            step.set_batch(*batches[it])
+            step.step()
+        ev = metric.drain(full=True)
+        assert len(first) == STEPS and len(ev) == 16
+        tot0 = np.mean([0.5 * e[2] + 0.5 * e[3] for e in first[:16]])
+        tot = np.mean([0.5 * e[2] + 0.5 * e[3] for e in ev])
+        acc = np.mean([e[0] for e in ev])
+        out[dt] = (tot0, tot, acc)
+        print('%s: total loss %.5f (first 16 steps) -> %.5f, PCK@0.5 %.3f after %d steps' % (dt, tot0, tot, acc, STEPS))
+        del step, student, teacher
+        torch.cuda.empty_cache()
+    (f0, l32, a32), (_, l16, a16) = out['fp32'], out['bf16']
+    assert l32 < 0.25 * f0 and a32 > 0.5, 'the fp32 run did not learn'
+    assert abs(l16 - l32) <= 0.05 * l32, ('final loss', l16, l32)
+    assert abs(a16 - a32) <= 0.02, ('final PCK', a16, a32)
