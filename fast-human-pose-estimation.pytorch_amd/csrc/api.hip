@@ -14,6 +14,8 @@ int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_conv_pp_option(int which, int value);
+int fpd_conv_pp_wgrad_partials(const fpd_conv_t& a);
+int fpd_conv_pp_pair_wgrad_partials(const fpd_conv_t& a, const fpd_conv_t& b, int* na, int* nb);
 int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_bneck_fused_launch(const fpd_bneck_t& a, hipStream_t st);
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st);
@@ -122,7 +124,9 @@ static int validate_conv(const fpd_conv_t* a) {
 
 static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     int rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent ping-pong kernel
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent kernel
+    FPD_REQUIRE(rc != 1 || a->wg_partial == nullptr, "conv: a fused weight gradient (wg_partial) needs the persistent kernel; "
+                "fpd_conv_fused_wgrad_partials() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_smallc_launch(*a, st);   // tiny input-channel counts (3, 17)
@@ -135,6 +139,20 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
     if (rc) return rc;
     rc = dispatch_conv(a, (hipStream_t)stream);
     return rc ? rc : check_launch();
+}
+
+int fpd_conv_fused_wgrad_partials(const fpd_conv_t* a) {
+    if (!a || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(a) != 0) return 0;
+    return fpd_conv_pp_wgrad_partials(*a);
+}
+int fpd_conv_pair_fused_wgrad_partials(const fpd_conv_pair_t* p, int32_t* n_a, int32_t* n_b) {
+    FPD_REQUIRE(p && n_a && n_b, "conv_pair_fused_wgrad_partials: null pointer");
+    *n_a = *n_b = 0;
+    if (g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(&p->a) != 0 || validate_conv(&p->b) != 0) return 0;
+    int na = 0, nb = 0;
+    fpd_conv_pp_pair_wgrad_partials(p->a, p->b, &na, &nb);
+    *n_a = na; *n_b = nb;
+    return 0;
 }
 
 int fpd_conv_f8_in_domain(const fpd_conv_t* c) { return (c && fpd_conv_f8_domain(*c)) ? 1 : 0; }
@@ -166,6 +184,8 @@ int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
+    FPD_REQUIRE(rc != 1 || (p->a.wg_partial == nullptr && p->b.wg_partial == nullptr),
+                "conv_pair: fused weight gradients need the persistent kernel; fpd_conv_pair_fused_wgrad_partials() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);
     if (rc == 1) {                       // not pairable: same result from two launches
         rc = dispatch_conv(&p->a, st);

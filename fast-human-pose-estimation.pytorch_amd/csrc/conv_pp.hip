@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "conv_epilogue.h"
+#include "mfma_frag.h"
 
 namespace {
 
@@ -59,7 +60,10 @@ __device__ __forceinline__ int pp_fresh(int v) {
 #endif
 
 // KH = 2: tile = 128 pixels x 64 channels (wave = pixel group w % 4, channel half w / 4); KH = 1: 256 pixels x 32 channels
-template <int R, int C, int KH, bool BWD>
+// WG (BWD, 1x1 only): the launch also forms the weight / bias gradient of the forward convolution it is the data gradient of
+// (fpd_conv_t.wg_partial): dW[k][c] = sum_p dy[p][k] * a(u)[p][c] from the operand image (dy, pixel-major in the LDS anyway) and
+// the forward operand a(u) = relu?(bn(u)) the epilogue evaluates for its ReLU mask -- both through transposing LDS reads.
+template <int R, int C, int KH, bool BWD, bool WG>
 __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo geo, const int bi, const int n0) {
     constexpr int RS = R * R, KP = 32 * KH, PXW = 8 / KH, CPR = C / 8, LOG_CPR = pp_ilog2(CPR), KS = C / 16;
     constexpr int LDA = C * 2 + 16;                       // operand-image pixel pitch in BYTES (16 B pad: conflict-free b128 reads)
@@ -68,6 +72,10 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     constexpr int pad = (R - 1) / 2;
     constexpr int RPB = CPR >= 16 ? 1 : 16 / CPR;         // weight rows per 256-byte bank row
     constexpr int NWV = (KP * RS * CPR + 511) / 512;      // weight vectors per thread
+    constexpr int LDAT = KP * 2 + 16;                     // WG: pitch of the forward-operand tile [px][KP] bf16
+    constexpr int NTILE = WG ? (C / 32) * KH : 1;         // WG: 32x32 tiles of dW this block owns (k tiles x c tiles)
+    constexpr int NPART = WG ? 8 / NTILE : 1;             // WG: waves per tile, splitting the pixel steps
+    static_assert(!WG || (BWD && R == 1 && C >= 32 && NTILE * NPART == 8), "fused weight gradient: 1x1 data gradients only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -85,8 +93,11 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     float* s_bias = s_epi + 4 * KP;                       // [KP]
     unsigned char* sW = reinterpret_cast<unsigned char*>(s_bias + KP);
     unsigned char* sG = sW + RS * KP * C * 2;             // operand image; the waves' epilogue staging tiles alias it
+    unsigned char* sS = WG ? sG + geo.region : sG;        // ... unless the weight gradient needs the image after the epilogue
+    unsigned char* sAT = sS + 8 * 32 * LDST;              // WG: a(u) tile
+    const bool wg = WG && a.wg_partial != nullptr;
 #ifdef FPD_PP_TIMING
-    long long* s_stamp = reinterpret_cast<long long*>(sG + geo.region);
+    long long* s_stamp = reinterpret_cast<long long*>(sG + geo.region + (WG ? 8 * 32 * LDST + 32 * PXW * LDAT : 0));
     int s_ns = 0;
     if (tid < 100) s_stamp[tid] = 0;
     __syncthreads();
@@ -128,6 +139,10 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         }
     };
     const float relu_lo = a.bn.relu ? 0.f : -3.4e38f;
+    float bs[8];                                          // WG: this thread's share of sum_pixels dy[., 8 channels]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    const bool wg_bias = wg && a.wg_bias && n0 == 0;
     auto halo_store = [&]() {
         const int tl = pp_fresh(tid);
         const int cvb = (tl & (CPR - 1)) * 16;
@@ -157,6 +172,13 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                 const int hr = pp_qdiv(vc, geo.mWV);
                 const int j = (vc - hr * WV) >> LOG_CPR;
                 uint4 val = rh[i];
+                if (WG && wg_bias) {
+                    float f[8];
+                    DT<bf16_t>::unpack(val, f);
+                    const float cnt = (v < nvtot && ((hmask >> i) & 1u)) ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs[e] = fmaf(f[e], cnt, bs[e]);
+                }
                 if (has_bn) {
                     float f[8];
                     DT<bf16_t>::unpack(val, f);
@@ -244,10 +266,13 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         }
     };
     f32x16 acc;
+    f32x16 wacc;                                          // WG: this wave's 32x32 tile of dW (its share of the pixel steps)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
     auto epilogue = [&](int tile, const bool first) {
         const int ln = pp_fresh(lane);
         const int cv4 = ln & 3, r16 = ln >> 2;
-        unsigned char* stg = sG + wave * (32 * LDST);     // wave-private [32 px][LDST]
+        unsigned char* stg = sS + wave * (32 * LDST);     // wave-private [32 px][LDST]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v;
@@ -268,6 +293,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             const unsigned rr[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
             const unsigned xr[4] = {rex[BWD ? it : 0].x, rex[BWD ? it : 0].y, rex[BWD ? it : 0].z, rex[BWD ? it : 0].w};
             unsigned pw[4];
+            unsigned aw[4] = {0u, 0u, 0u, 0u};            // WG: bf16 a(u) of this row's 8 channels
             // 4 channels at a time; the per-channel tables are re-read from the LDS (laundered address) instead of living in
             // registers across the tile loop: v = acc + residual + bias, rounded once
 #pragma unroll
@@ -301,6 +327,14 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                         xv[e] = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
                         const float z = fmaf(xv[e], esc[e], esh[e]);
                         v[e] = (z > relu_gate) ? v[e] : 0.f;
+                    }
+                    if (WG) {
+                        // the forward operand exactly as the forward convolution staged it: bf16(max(fma(u, scale, shift), lo))
+                        float az[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) az[e] = fmaxf(fmaf(xv[e], esc[e], esh[e]), relu_gate);
+                        aw[2 * q] = ok ? f2bf_pk(az[0], az[1]) : 0u;
+                        aw[2 * q + 1] = ok ? f2bf_pk(az[2], az[3]) : 0u;
                     }
                     pw[2 * q] = f2bf_pk(v[0], v[1]);
                     pw[2 * q + 1] = f2bf_pk(v[2], v[3]);
@@ -347,6 +381,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             }
             if (want_stats && ok) ++nrow;
             if (ok) *reinterpret_cast<uint4*>(y + ((size_t)m * K + k0)) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            if (WG) *reinterpret_cast<uint4*>(sAT + px * LDAT + kl * 2) = make_uint4(aw[0], aw[1], aw[2], aw[3]);
             __builtin_amdgcn_sched_barrier(0);            // one row at a time: interleaving both rows doubles the live temporaries
         }
     };
@@ -377,12 +412,67 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             }
         }
         PP_STAMP();
-        __syncthreads();                                  // every wave is done reading the image: staging tiles may overwrite it
+        if (!WG) __syncthreads();                         // every wave is done reading the image: staging tiles may overwrite it
         PP_STAMP();
         epilogue(tile, tile == t_beg);
         PP_STAMP();
         __syncthreads();                                  // staging tiles read back: the next operand image may overwrite them
-        PP_STAMP();
+        PP_STAMP();                                       // (WG: and the a(u) tile is complete)
+        if (WG) {
+            if (wg) {
+                const int tw = wave % NTILE, part = wave / NTILE;
+                const int tkf = tw / KH, tcf = tw % KH;
+                const int nks = TPX >> 4;                 // pixel steps of 16 (TPX % 16 == 0: checked by the host)
+                for (int ks = part; ks < nks; ks += NPART) {
+                    const bf16x8 af = tr_frag_bf16(reinterpret_cast<const bf16_t*>(sG), LDA / 2, ks * 16, tkf * 32, lane);
+                    const bf16x8 bf = tr_frag_bf16(reinterpret_cast<const bf16_t*>(sAT), LDAT / 2, ks * 16, tcf * 32, lane);
+                    wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, wacc, 0, 0, 0);
+                }
+            }
+            __syncthreads();                              // image + a(u) tile free for the next tile
+        }
+    }
+
+    // ---- WG: weight / bias gradient partial sums of this block -> its slab ----
+    if (WG && wg) {
+        const int tw = wave % NTILE, part = wave / NTILE;
+        const int tkf = tw / KH, tcf = tw % KH;
+        float* s_w = reinterpret_cast<float*>(sS);        // [8 waves][16][64] (the staging tiles are free)
+        if (NPART > 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_w[(wave * 16 + e) * 64 + lane] = wacc[e];
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int q = 1; q < NPART; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) wacc[e] += s_w[((tw + q * NTILE) * 16 + e) * 64 + lane];
+            }
+        }
+        float* slab = a.wg_partial + (size_t)bi * a.wg_stride;
+        if (part == 0) {
+            const int cf = n0 + tcf * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kf = tkf * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (cf < K) slab[(size_t)kf * K + cf] = wacc[e];
+            }
+        }
+        if (wg_bias) {
+            // threads t, t + CPR, ... hold partial sums of the same 8 channels: fixed-order sum through the LDS
+            __syncthreads();
+            float* s_b = reinterpret_cast<float*>(sS);    // [512][8]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_b[tid * 8 + e] = bs[e];
+            __syncthreads();
+            if (tid < C) {
+                const int ch = tid >> 3, e = tid & 7;
+                float tot = 0.f;
+                for (int t = ch; t < 512; t += CPR) tot += s_b[t * 8 + e];
+                slab[(size_t)C * K + tid] = tot;
+            }
+        }
+        __syncthreads();                                  // staging region free for the statistics flush
     }
 
     // ---- statistics: one flush per block ----
@@ -392,7 +482,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     // ds_bpermute round trips, 3 us at the end of every block), un-shifted once in fp64, then the waves of a channel half
     // are added in a fixed order and ONE fp64 atomic pair per channel leaves the block.
     if (want_stats) {
-        float* rec = reinterpret_cast<float*>(sG + wave * (32 * LDST));      // [64 lanes][17]: f1[8] f2[8] nrow
+        float* rec = reinterpret_cast<float*>(sS + wave * (32 * LDST));      // [64 lanes][17]: f1[8] f2[8] nrow
 #pragma unroll
         for (int e = 0; e < 8; ++e) { rec[lane * 17 + e] = f1[e]; rec[lane * 17 + 8 + e] = f2[e]; }
         rec[lane * 17 + 16] = (float)nrow;
@@ -419,7 +509,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         const double s1 = (double)t1 + n * c;
         const double s2 = BWD ? (double)t2 : (double)t2 + 2.0 * c * (double)t1 + n * c * c;
         __syncthreads();                                                     // every wave is done with its staging tile
-        double* s_red = reinterpret_cast<double*>(sG);                       // [8 waves][32][2]
+        double* s_red = reinterpret_cast<double*>(sS);                       // [8 waves][32][2]
         if (lane < 32) {
             s_red[(wave * 32 + lane) * 2 + 0] = s1;
             s_red[(wave * 32 + lane) * 2 + 1] = s2;
@@ -461,7 +551,7 @@ struct PPArgs { fpd_conv_t c[2]; PPGeo g[2]; int ks; };
 
 // Forward kernels fit 128 registers per lane (two blocks per CU); the BN-backward epilogue (epi_x prefetch, mask, two more sums)
 // does not without spilling the operand prefetch to scratch, so those kernels take the 256-register budget and one block per CU.
-template <int R, int C, int KH, bool BWD>
+template <int R, int C, int KH, bool BWD, bool WG>
 __global__ __launch_bounds__(512, BWD ? 2 : 4) void conv_pp_kernel(const PPArgs p) {
     const int bid = blockIdx.x, n = gridDim.x, ks = p.ks, nb = p.g[1].nblk * ks;
     const int fb0 = (int)((long long)bid * nb / n), fb1 = (int)((long long)(bid + 1) * nb / n);
@@ -471,7 +561,7 @@ __global__ __launch_bounds__(512, BWD ? 2 : 4) void conv_pp_kernel(const PPArgs 
     int range, slab;
     if (ks == 2 && (nr & 7) == 0) { slab = (u >> 3) & 1; range = (u & 7) + 8 * (u >> 4); }
     else { slab = u % ks; range = u / ks; }
-    conv_pp_body<R, C, KH, BWD>(p.c[isb], p.g[isb], range, slab * 64);
+    conv_pp_body<R, C, KH, BWD, WG>(p.c[isb], p.g[isb], range, slab * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -480,8 +570,8 @@ constexpr size_t PP_LDS_MAX = 160 * 1024;
 // FPD_CONV_PP: 0 = never, 1 = launches with >= FPD_CONV_PP_MIN_TILES (256) pixel tiles (default), 2 = whenever the shape is in
 // the domain; FPD_CONV_PP_BLOCKS: persistent blocks per occupancy slot (default 128: the grid is that times the blocks a CU can
 // hold, at most 2 -- r03 sweep inside the pipelined step, one box: 64/96/128/256 x 2 -> 12.38/11.41/11.00/11.01 ms, 128/192/256 x 1
-// -> 11.35/11.12/11.03; threshold 512/256/128 tiles -> 11.00/10.79/10.78; conv_tile only: 11.50).  Both can be changed at run time through fpd_set_option("conv_pp" / "conv_pp_blocks", v)
-// (tests drive small shapes through the kernel that way).
+// -> 11.35/11.12/11.03; threshold 512/256/128 tiles -> 11.00/10.79/10.78; conv_tile only: 11.50).  mode / blocks can be changed
+// at run time through fpd_set_option("conv_pp" / "conv_pp_blocks", v) (tests drive small shapes through the kernel that way).
 static int g_pp_mode = -1, g_pp_blocks = -1;
 static int pp_mode() {
     if (g_pp_mode < 0) { const char* e = getenv("FPD_CONV_PP"); g_pp_mode = e ? atoi(e) : 1; }
@@ -501,6 +591,11 @@ static int pp_occ_cap() {    // FPD_CONV_PP_OCC: resident blocks per CU the grid
     if (v < 0) { const char* e = getenv("FPD_CONV_PP_OCC"); v = e ? atoi(e) : 2; }
     return v < 1 ? 1 : v;
 }
+static int pp_fuse_wgrad() { // FPD_CONV_PP_WGRAD: 0 = never fuse the weight gradient into the data-gradient launch
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD"); v = e ? atoi(e) : 1; }
+    return v;
+}
 
 static int pp_tile_px(const fpd_conv_t& a) { return a.K > 32 ? 128 : 256; }
 static int pp_nrows(const fpd_conv_t& a) { return std::max(1, pp_tile_px(a) / a.W); }
@@ -515,10 +610,14 @@ static bool pp_domain(const fpd_conv_t& a) {
     return true;
 }
 static int pp_tiles(const fpd_conv_t& a) { return cdiv(a.N * a.H, pp_nrows(a)); }
+// shapes whose data-gradient launch can carry the forward convolution's weight gradient (conv_pp_body<.., WG = true>)
+static bool pp_wg_shape(const fpd_conv_t& a) {
+    return pp_fuse_wgrad() != 0 && pp_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && a.R == 1 && a.C >= 32 &&
+           (pp_nrows(a) * a.W) % 16 == 0;
+}
 
-template <int C>
 static PPGeo pp_geo(const fpd_conv_t& a) {
-    constexpr int LDST = 32 * 4 + 16, LDA = C * 2 + 16;
+    const int LDST = 32 * 4 + 16, LDA = a.C * 2 + 16;
     PPGeo g;
     g.nrows = pp_nrows(a);
     g.ntiles = pp_tiles(a);
@@ -526,73 +625,111 @@ static PPGeo pp_geo(const fpd_conv_t& a) {
     const int hrows = g.nrows + a.R - 1, WP = a.W + a.R - 1;
     g.region = std::max((hrows * WP + 4) * LDA, 8 * 32 * LDST);
     g.mW = pp_magic(a.W);
-    g.mWV = pp_magic(a.W * (C / 8));
+    g.mWV = pp_magic(a.W * (a.C / 8));
     g.mH = pp_magic(a.H);
     return g;
 }
 
-template <int R, int C, int KH, bool BWD>
-static int pp_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
-    PPGeo ga = pp_geo<C>(a), gb = ga;
-    fpd_conv_t bb = a;
-    gb.nblk = 0;
-    int total = ga.ntiles;
+// launch geometry of one convolution (b == nullptr) or a pair: ONE place decides it, for the launch and for the slab-count query
+struct PPPlan { PPGeo ga, gb; int ks, grid; size_t lds; bool wg; };
+static bool pp_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, PPPlan& pl) {
+    const int KH = a.K > 32 ? 2 : 1;
+    const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
+    pl.ga = pp_geo(a);
+    pl.gb = pl.ga;
+    pl.gb.nblk = 0;
+    int total = pl.ga.ntiles;
     if (b != nullptr) {
-        gb = pp_geo<C>(*b);
-        bb = *b;
-        total += gb.ntiles;
+        pl.gb = pp_geo(*b);
+        total += pl.gb.ntiles;
     }
-    const int region = std::max(ga.region, b ? gb.region : 0);
-    ga.region = gb.region = region;
-    size_t lds = (size_t)(2 * C + 5 * 32 * KH) * sizeof(float) + (size_t)R * R * 32 * KH * C * 2 + (size_t)region;
+    pl.wg = want_wg && pp_wg_shape(a) && (b == nullptr || pp_wg_shape(*b));
+    int region = std::max(pl.ga.region, b ? pl.gb.region : 0);
+    if (pl.wg) {                                           // the image is not aliased: only the image counts
+        const int LDA = a.C * 2 + 16;
+        auto img = [&](const fpd_conv_t& c, const PPGeo& g) { return (g.nrows * c.W + 4) * LDA; };
+        region = std::max(img(a, pl.ga), b ? img(*b, pl.gb) : 0);
+    }
+    pl.ga.region = pl.gb.region = region;
+    pl.lds = (size_t)(2 * a.C + 5 * 32 * KH) * sizeof(float) + (size_t)a.R * a.R * 32 * KH * a.C * 2 + (size_t)region;
+    if (pl.wg) pl.lds += (size_t)8 * 32 * (32 * 4 + 16) + (size_t)(256 / KH) * (32 * KH * 2 + 16);
 #ifdef FPD_PP_TIMING
-    lds += 1024;
+    pl.lds += 1024;
 #endif
-    if (lds > PP_LDS_MAX) return 1;
-    const int occ = BWD ? 1 : std::max(1, std::min(pp_occ_cap(), (int)(PP_LDS_MAX / lds)));
-    const int ks = cdiv(a.K, 64);                          // channel slabs of <= 64 (K = 128: two blocks per tile range)
+    if (pl.lds > PP_LDS_MAX) return false;
+    const int occ = bwd ? 1 : std::max(1, std::min(pp_occ_cap(), (int)(PP_LDS_MAX / pl.lds)));
+    pl.ks = cdiv(a.K, 64);                                 // channel slabs of <= 64 (K = 128: two blocks per tile range)
     // tile ranges: ks blocks per range, every block should own at least two tiles
-    int ranges = std::max(1, std::min(pp_blocks() * occ / ks, total / 2));
+    int ranges = std::max(1, std::min(pp_blocks() * occ / pl.ks, total / 2));
     if (b != nullptr) {
-        if (ranges < 2) return 1;
-        gb.nblk = std::max(1, std::min(ranges - 1, (int)((long long)ranges * gb.ntiles / total)));
+        if (ranges < 2) return false;
+        pl.gb.nblk = std::max(1, std::min(ranges - 1, (int)((long long)ranges * pl.gb.ntiles / total)));
     }
-    ga.nblk = ranges - gb.nblk;
-    if (ks == 2 && ga.nblk >= 8) ga.nblk &= ~7;            // (the XCD pairing of the slabs wants multiples of 8)
-    if (ks == 2 && gb.nblk >= 8) gb.nblk &= ~7;
-    const int grid = (ga.nblk + gb.nblk) * ks;
+    pl.ga.nblk = ranges - pl.gb.nblk;
+    if (pl.ks == 2 && pl.ga.nblk >= 8) pl.ga.nblk &= ~7;   // (the XCD pairing of the slabs wants multiples of 8)
+    if (pl.ks == 2 && pl.gb.nblk >= 8) pl.gb.nblk &= ~7;
+    pl.grid = (pl.ga.nblk + pl.gb.nblk) * pl.ks;
+    return true;
+}
+
+template <int R, int C, int KH, bool BWD, bool WG>
+static int pp_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, const PPPlan& pl, hipStream_t st) {
     static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, KH, BWD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
+    if (pl.lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, KH, BWD, WG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", pl.lds, hipGetErrorString(e));
+        configured = pl.lds;
     }
     PPArgs args;
-    args.c[0] = a; args.c[1] = bb; args.g[0] = ga; args.g[1] = gb; args.ks = ks;
-    hipLaunchKernelGGL((conv_pp_kernel<R, C, KH, BWD>), dim3(grid), dim3(512), lds, st, args);
+    args.c[0] = a; args.c[1] = b ? *b : a; args.g[0] = pl.ga; args.g[1] = pl.gb; args.ks = pl.ks;
+    hipLaunchKernelGGL((conv_pp_kernel<R, C, KH, BWD, WG>), dim3(pl.grid), dim3(512), pl.lds, st, args);
     return 0;
 }
 
 template <int R, int C>
-static int pp_launch_c(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
+static int pp_launch_c(const fpd_conv_t& a, const fpd_conv_t* b, const PPPlan& pl, hipStream_t st) {
     const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
-    if (a.K > 32) return bwd ? pp_launch_t<R, C, 2, true>(a, b, st) : pp_launch_t<R, C, 2, false>(a, b, st);
-    return bwd ? pp_launch_t<R, C, 1, true>(a, b, st) : pp_launch_t<R, C, 1, false>(a, b, st);
+    if constexpr (R == 1 && C >= 32) {
+        if (pl.wg) return a.K > 32 ? pp_launch_t<R, C, 2, true, true>(a, b, pl, st) : pp_launch_t<R, C, 1, true, true>(a, b, pl, st);
+    }
+    if (a.K > 32) return bwd ? pp_launch_t<R, C, 2, true, false>(a, b, pl, st) : pp_launch_t<R, C, 2, false, false>(a, b, pl, st);
+    return bwd ? pp_launch_t<R, C, 1, true, false>(a, b, pl, st) : pp_launch_t<R, C, 1, false, false>(a, b, pl, st);
 }
 
 static int pp_launch(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
+    const bool want_wg = a.wg_partial != nullptr || (b != nullptr && b->wg_partial != nullptr);
+    PPPlan pl;
+    if (!pp_plan(a, b, want_wg, pl)) return 1;
+    if (want_wg) {
+        if (!pl.wg) return fpd_fail(-2, "conv: a fused weight gradient was requested for a launch fpd_conv_fused_wgrad_partials() reports 0 for");
+        const fpd_conv_t* cs[2] = {&a, b};
+        for (int i = 0; i < 2; ++i)
+            if (cs[i] != nullptr && cs[i]->wg_partial != nullptr && cs[i]->wg_stride < (int64_t)cs[i]->C * cs[i]->K + cs[i]->C)
+                return fpd_fail(-2, "conv: wg_stride %lld smaller than weight + bias", (long long)cs[i]->wg_stride);
+    }
     if (a.R == 3) {
-        if (a.C == 64) return pp_launch_c<3, 64>(a, b, st);
-        if (a.C == 32) return pp_launch_c<3, 32>(a, b, st);
-        return pp_launch_c<3, 16>(a, b, st);
+        if (a.C == 64) return pp_launch_c<3, 64>(a, b, pl, st);
+        if (a.C == 32) return pp_launch_c<3, 32>(a, b, pl, st);
+        return pp_launch_c<3, 16>(a, b, pl, st);
     }
     switch (a.C) {
-        case 16: return pp_launch_c<1, 16>(a, b, st);
-        case 32: return pp_launch_c<1, 32>(a, b, st);
-        case 64: return pp_launch_c<1, 64>(a, b, st);
-        default: return pp_launch_c<1, 128>(a, b, st);
+        case 16: return pp_launch_c<1, 16>(a, b, pl, st);
+        case 32: return pp_launch_c<1, 32>(a, b, pl, st);
+        case 64: return pp_launch_c<1, 64>(a, b, pl, st);
+        default: return pp_launch_c<1, 128>(a, b, pl, st);
     }
+}
+
+static bool pp_takes(const fpd_conv_t& a, const fpd_conv_t* b) {
+    const int mode = pp_mode();
+    if (mode == 0 || !pp_domain(a)) return false;
+    int tiles = pp_tiles(a);
+    if (b != nullptr) {
+        if (!pp_domain(*b) || a.K != b->K || a.C != b->C || a.R != b->R || a.epi != b->epi) return false;
+        tiles += pp_tiles(*b);
+    }
+    return mode != 1 || tiles >= pp_min_tiles();
 }
 
 }  // namespace
@@ -606,17 +743,28 @@ int fpd_conv_pp_option(int which, int value) {     // which: 0 = mode, 1 = block
 
 // 0 = launched, 1 = outside this kernel's domain (the caller tries conv_tile next), < 0 error
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st) {
-    const int mode = pp_mode();
-    if (mode == 0 || !pp_domain(a)) return 1;
-    if (mode == 1 && pp_tiles(a) < pp_min_tiles()) return 1;
+    if (!pp_takes(a, nullptr)) return 1;
     return pp_launch(a, nullptr, st);
 }
 
 // two independent convolutions of equal channel shapes in one launch; 1 = not pairable here
 int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
-    const int mode = pp_mode();
-    if (mode == 0 || !pp_domain(a) || !pp_domain(b)) return 1;
-    if (a.K != b.K || a.C != b.C || a.R != b.R || a.epi != b.epi) return 1;
-    if (mode == 1 && pp_tiles(a) + pp_tiles(b) < pp_min_tiles()) return 1;
+    if (!pp_takes(a, &b)) return 1;
     return pp_launch(a, &b, st);
+}
+
+// slabs of the fused weight gradient (fpd_conv_t.wg_partial) for a single launch / the two halves of a pair launch; 0 = the
+// launch would not run here, or not with the fusion
+int fpd_conv_pp_wgrad_partials(const fpd_conv_t& a) {
+    PPPlan pl;
+    if (!pp_takes(a, nullptr) || !pp_plan(a, nullptr, true, pl) || !pl.wg) return 0;
+    return pl.ga.nblk;
+}
+int fpd_conv_pp_pair_wgrad_partials(const fpd_conv_t& a, const fpd_conv_t& b, int* na, int* nb) {
+    PPPlan pl;
+    *na = *nb = 0;
+    if (!pp_takes(a, &b) || !pp_plan(a, &b, true, pl) || !pl.wg) return 0;
+    *na = pl.ga.nblk;
+    *nb = pl.gb.nblk;
+    return 0;
 }

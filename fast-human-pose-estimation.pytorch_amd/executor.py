@@ -101,6 +101,7 @@ class Lowering:
         self.keep = []          # device tables that must outlive the plan
         self.use_partials = False
         self.partials, self.partial_elems = {}, 0      # id(IR wgrad op) -> slab record
+        self.fused = set()                             # id(IR wgrad op) computed inside its data-gradient launch (conv_pp)
         self.reduces = []                              # (IR wreduce op, its TableT) filled in by finish_partials()
 
     def bn(self, bn):
@@ -126,11 +127,30 @@ class Lowering:
         s.out_stats = p(op.out_stats)
         s.bn = self.bn(op.bn)
         s.epi_x, s.epi_bn, s.epi_stats = p(_abuf(op.epi_x)), self.bn(op.epi_bn), p(op.epi_stats)
+        s.wg_partial, s.wg_stride, s.wg_bias = None, 0, 0
+        if not plain and getattr(op, 'fused_wgrad', None) is not None and self.use_partials:
+            n = R.lib().fpd_conv_fused_wgrad_partials(C.byref(s))
+            if n > 0:
+                self._fuse_wgrad(op, s, n)
         if getattr(op, 'w8', None) is not None and not plain:
             f = R.ConvF8T()
             f.c, f.w8, f.w8_scale = s, p(op.w8), p(op.w8s)
             return R.OP_CONV_F8, f
         return R.OP_CONV, s
+
+    def _fuse_wgrad(self, op, s, n):
+        """The data-gradient launch `op` (struct `s`, a ConvT -- possibly a field of a pair struct) also forms the weight
+        gradient of `op.fused_wgrad` into `n` slabs: register them like a weight-gradient kernel's (finish_partials patches
+        the struct, the bucket's 'wreduce' sums them) and turn the separate 'wgrad' op into a no-op."""
+        fw = op.fused_wgrad
+        numel = fw.dw.numel                                 # [Kf][1][1][Cf] = [s.C][s.K]
+        assert numel == s.C * s.K, (numel, s.C, s.K)
+        stride = (numel + s.C + 63) // 64 * 64              # weight slab + bias partials
+        self.partials[id(fw)] = [s, fw.dw, numel, stride, n, self.partial_elems, fw.dbias, s.C]
+        self.partial_elems += n * stride
+        s.wg_bias = 1 if fw.dbias is not None else 0
+        self.fused.add(id(fw))
+        op.fused_active = True
 
     def wquant(self, entries):
         """[(master weight Buf, e4m3 Buf, scale Buf)] -> one table-driven launch (fpd_weight_quant_f8)."""
@@ -168,6 +188,8 @@ class Lowering:
         return R.OP_HEAD, s
 
     def wgrad(self, op):
+        if id(op) in self.fused:                           # formed by the data-gradient launch (fpd_conv_t.wg_partial)
+            return R.OP_NOP, R.MemsetT()
         s = R.WgradT()
         (s.N, s.H, s.W, s.C, s.K, s.R, s.S, s.stride, s.pad, s.P, s.Q) = op.dims
         s.dtype = self.dtype
@@ -181,7 +203,7 @@ class Lowering:
             if n > 0:
                 numel = op.dw.numel
                 stride = (numel + s.K + 63) // 64 * 64          # weight slab + bias partials
-                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias]
+                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias, s.K]
                 self.partial_elems += n * stride
         return R.OP_WGRAD, s
 
@@ -201,22 +223,25 @@ class Lowering:
             return
         ws = torch.empty(self.partial_elems, dtype=torch.float32, device=self.A.device)
         self.keep.append(ws)
-        for s, dw, numel, stride, n, off, dbias in self.partials.values():
-            s.partial = ws.data_ptr() + 4 * off
-            s.partial_stride = stride
+        for s, dw, numel, stride, n, off, dbias, nbias in self.partials.values():
+            if isinstance(s, R.ConvT):                    # fused into a data-gradient launch
+                s.wg_partial, s.wg_stride = ws.data_ptr() + 4 * off, stride
+            else:
+                s.partial, s.partial_stride = ws.data_ptr() + 4 * off, stride
         for op, t in self.reduces:
             ents, mx = [], 0
             for w in op.wgrads:
                 rec = self.partials.get(id(w))
                 if rec is None:
                     continue
-                s, dw, numel, stride, n, off, dbias = rec
+                s, dw, numel, stride, n, off, dbias, nbias = rec
+                base = ws.data_ptr() + 4 * off
                 e = R.WreduceEntryT()
-                e.partial, e.dw, e.n, e.stride, e.count = s.partial, self.A.ptr(dw), numel, stride, n
+                e.partial, e.dw, e.n, e.stride, e.count = base, self.A.ptr(dw), numel, stride, n
                 ents.append(e)
                 if dbias is not None:
                     e = R.WreduceEntryT()
-                    e.partial, e.dw, e.n, e.stride, e.count = s.partial + 4 * numel, self.A.ptr(dbias), s.K, stride, n
+                    e.partial, e.dw, e.n, e.stride, e.count = base + 4 * numel, self.A.ptr(dbias), nbias, stride, n
                     ents.append(e)
                 mx = max(mx, numel)
             t.table, t.n, t.dtype, t.max_elems = self._table(ents, R.WreduceEntryT), len(ents), self.dtype, mx
@@ -237,7 +262,7 @@ class Lowering:
             if n > 0:
                 numel = op.dw.numel
                 stride = (numel + s.K + 63) // 64 * 64
-                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias]
+                self.partials[id(op)] = [s, op.dw, numel, stride, n, self.partial_elems, op.dbias, s.K]
                 self.partial_elems += n * stride
         return R.OP_STEM_WGRAD, s
 
@@ -294,6 +319,13 @@ class Lowering:
         if op.kind == 'conv2':
             s = R.ConvPairT()
             s.a, s.b = self.conv(op.a, plain=True)[1], self.conv(op.b, plain=True)[1]
+            if (self.use_partials and getattr(op.a, 'fused_wgrad', None) is not None and
+                    getattr(op.b, 'fused_wgrad', None) is not None):
+                na, nb = C.c_int32(0), C.c_int32(0)
+                R.check(R.lib().fpd_conv_pair_fused_wgrad_partials(C.byref(s), C.byref(na), C.byref(nb)), 'fpd_conv_pair_fused_wgrad_partials')
+                if na.value > 0 and nb.value > 0:          # s.a / s.b are views INTO the pair struct: patched in place later
+                    self._fuse_wgrad(op.a, s.a, na.value)
+                    self._fuse_wgrad(op.b, s.b, nb.value)
             return R.OP_CONV_PAIR, s
         if op.kind == 'ew2':
             s = R.EwPairT()

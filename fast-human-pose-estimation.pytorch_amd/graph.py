@@ -112,6 +112,9 @@ class Op:
             rd = [b(self.x), self.w, self.bias, b(self.residual), b(self.epi_x)] + bn_bufs(self.bn) + bn_bufs(self.epi_bn)
             rd += [getattr(self, 'w8', None), getattr(self, 'w8s', None)]
             wr = [b(self.y), self.out_stats, self.epi_stats]
+            fw = getattr(self, 'fused_wgrad', None)        # this data gradient also writes the slabs of that weight gradient
+            if fw is not None and getattr(self, 'fused_active', False):
+                wr += [fw.dw, fw.dbias]
         elif k == 'head':
             rd = [b(self.y0), b(self.x), self.w_fc, self.b_fc, self.w_score, self.b_score, self.w_fc2, self.b_fc2,
                   self.w_score2, self.b_score2] + bn_bufs(self.bn)
@@ -764,10 +767,18 @@ class HourglassGraph:
             assert stride == 1
         wb = self.wbwd[op.wkey]
         if op.bn is not None:
+            wg = self._wg_pending[-1]
+
             def make(dz, add, bstats, op=op, dy=dy, x=x):
-                self._emit_dgrad(Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=dz,
-                                    out_stats=None, bn=None, epi='bnrelu_bwd', epi_x=x, epi_bn=op.bn, epi_stats=bstats,
-                                    dims=ddims))
+                d = Op('conv', x=dy, w=wb, wkey=op.wkey, bias=None, bkey=None, residual=add, y=dz,
+                       out_stats=None, bn=None, epi='bnrelu_bwd', epi_x=x, epi_bn=op.bn, epi_stats=bstats,
+                       dims=ddims)
+                # The data gradient of a 1x1 convolution reads dy and the forward operand's source anyway: where the library
+                # offers it (fpd_conv_fused_wgrad_partials, asked at lowering time) the launch also forms that convolution's
+                # weight gradient and the separate 'wgrad' op becomes a no-op (executor.Lowering.conv).
+                if R == 1 and stride == 1 and dy is op.y.grad:
+                    d.fused_wgrad = wg
+                self._emit_dgrad(d)
             self._bn_backward_contribution(x, op.bn, make)
         else:
             add, out = self._contribute(x)

@@ -80,6 +80,17 @@ typedef struct {
     const void* epi_x;     /* BNRELU_BWD: forward tensor normalised by epi_bn, [N,P,Q,K] */
     fpd_bn_t epi_bn;       /* BNRELU_BWD: its (train-mode) BN */
     double* epi_stats;     /* BNRELU_BWD: [R][2][K] += {sum dz, sum dz*xhat} */
+    /* FUSED WEIGHT GRADIENT (optional; BNRELU_BWD data gradient of a 1x1 convolution only): this launch is the data gradient
+     * of a forward convolution y = W * a(u), a(u) = relu?(bn(u)); it reads x = dy and epi_x = u anyway, so it can form the
+     * forward convolution's weight gradient dW[k][c] = sum_pixels dy[.,k] * a(u)[.,c] (k < C of this launch, c < K of this
+     * launch) and bias gradient sum_pixels dy[.,k] on the way, saving the separate fpd_conv_wgrad() launch and its HBM reads.
+     * Persistent block range b stores its partial sums to wg_partial + b*wg_stride (layout [C][K] floats, then [C] bias
+     * sums when wg_bias); fpd_wgrad_reduce() adds the slabs in order.  The number of slabs is fpd_conv_fused_wgrad_partials()
+     * (0 = this shape / configuration is not served: leave wg_partial NULL and call fpd_conv_wgrad()). */
+    float* wg_partial;
+    int64_t wg_stride;     /* floats between slabs, >= C*K + C */
+    int32_t wg_bias;       /* also accumulate the bias gradient */
+    int32_t _pad2;
 } fpd_conv_t;
 
 /* A whole pre-activation Bottleneck of a FROZEN network in one launch (hourglass.py:32-52 with eval-mode BN, no
@@ -293,6 +304,10 @@ int fpd_bottleneck_forward(const fpd_bneck_t* a, fpd_stream_t stream);
 /* writes a->folded (must be non-NULL) from a's BN / bias pointers; rerun whenever those parameters change */
 int fpd_bottleneck_fold(const fpd_bneck_t* a, fpd_stream_t stream);
 int fpd_bottleneck_forward_pair(const fpd_bneck_pair_t* p, fpd_stream_t stream);
+/* slabs the fused weight gradient of data-gradient launch `a` writes (see fpd_conv_t.wg_partial); 0 = not available.  For the
+ * two convolutions of a pair launch: fpd_conv_pair_fused_wgrad_partials (counts for p->a and p->b; returns 0 / error code). */
+int fpd_conv_fused_wgrad_partials(const fpd_conv_t* a);
+int fpd_conv_pair_fused_wgrad_partials(const fpd_conv_pair_t* p, int32_t* n_a, int32_t* n_b);
 int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
 int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writes when a->partial is set */
 int fpd_wgrad_reduce(const fpd_wreduce_entry_t* table_dev, int32_t n_entries, int64_t max_elems, fpd_stream_t stream);

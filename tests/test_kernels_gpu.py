@@ -89,6 +89,7 @@ class Bench:
         for code, st in lowered:
             plan.add(code, st)
         self.n_partial_ops = len(low.partials)
+        self.n_fused = len(low.fused)
         R.set_backend(prev)
         prev = R.set_backend(backend)
         try:
@@ -256,6 +257,45 @@ def test_conv_pp_dgrad(case):
     bt.realise().run(ops, ('pp', blocks))
     bt.compare(prev, label='conv_pp dgrad dz %s' % (case,), **TOL[1])
     bt.compare(bst, atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='conv_pp dgrad bn sums')
+
+
+@pytest.mark.parametrize('case', [(4, 64, 64, 128, 64, 8, True), (4, 64, 64, 64, 128, 8, True), (2, 64, 64, 128, 128, 5, True),
+                                  (1, 128, 128, 32, 32, 6, True), (2, 128, 128, 32, 64, 7, False), (3, 20, 48, 64, 32, 3, True),
+                                  (2, 32, 32, 128, 64, 4, True)])
+def test_conv_pp_dgrad_with_fused_weight_gradient(case):
+    """The persistent kernel's data gradient of a 1x1 convolution also forms that convolution's weight / bias gradient
+    (fpd_conv_t.wg_partial: dy is its operand image, relu(bn(u)) falls out of the ReLU-mask evaluation): the separate
+    'wgrad' op must become a no-op and dw / dbias must match the specification of the un-fused op."""
+    N, H, W, C, K, blocks, bias = case                    # forward convolution C -> K (1x1)
+    gen = torch.Generator().manual_seed(37 + sum(case[:6]))
+    bt = Bench(1)
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act((N, H, W, C), x_val, 'x')
+    dy = bt.act((N, H, W, K), rnd(gen, N, H, W, K, scale=0.1), 'dy')
+    wm = bt.buf('param', (K, 1, 1, C), rnd(gen, K, 1, 1, C, scale=1.0 / np.sqrt(C)))
+    wb = bt.buf('wlp', (C, 1, 1, K))
+    prev = bt.act((N, H, W, C), 0.5 * rnd(gen, N, H, W, C), 'prev')
+    dz = bt.act((N, H, W, C), None, 'dz')
+    bn = make_bn(bt, gen, C, 'train')
+    bn.count = N * H * W
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x_val.to(torch.bfloat16).float()))
+    bst = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
+    dw = bt.buf('grad', (K, 1, 1, C), torch.zeros(K, 1, 1, C))
+    db = bt.buf('grad', (K,), torch.zeros(K)) if bias else None
+    wg = G.Op('wgrad', x=x, dy=dy, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, 1, 1, 1, 0, H, W))
+    dg = G.Op('conv', x=dy, w=wb, wkey='w', bias=None, bkey=None, residual=prev, y=dz, out_stats=None, bn=None,
+              epi='bnrelu_bwd', epi_x=x, epi_bn=bn, epi_stats=bst, dims=(N, H, W, K, C, 1, 1, 1, 0, H, W))
+    dg.fused_wgrad = wg
+    ops = [G.Op('wprep', entries=[{'w': wm, 'w_fwd': None, 'w_bwd': wb}]), dg, wg]
+    bt.realise().run(ops, ('pp', blocks), partials=True)
+    assert bt.n_fused == 1 and getattr(dg, 'fused_active', False), 'the weight gradient was not fused into the data gradient'
+    bt.compare(dz, label='fused dgrad dz %s' % (case,), **TOL[1])
+    bt.compare(bst, atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='fused dgrad bn sums')
+    m = N * H * W
+    tol = dict(atol=2e-2 + 2e-5 * m, rtol=3e-2)
+    bt.compare(dw, label='fused wgrad dw %s' % (case,), **tol)
+    if bias:
+        bt.compare(db, label='fused wgrad dbias', **tol)
 
 
 def test_conv_pp_equals_conv_tile_bitwise():
