@@ -108,8 +108,17 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     const int H = a.H, W = a.W;
     const int M = a.N * H * W, GR = a.N * H;
     const int nrows = 128 >> logW, hrows = nrows + 2, WP = W + 2;
-    const int zero_px = hrows * WP;
+    // The a2 image is a RING of 2*nrows rows (two half-slots of nrows rows): halo row hr of tile T is "virtual row"
+    // T*nrows + hr and lives in ring row (T*nrows + hr) mod 2*nrows.  Consecutive tiles of one image share two halo rows and the
+    // ring keeps what the previous tile computed: tile T+1 only runs conv1 over its nrows NEW rows (one 128-pixel pass instead
+    // of two: phase A was 40 % of a tile at 2x recompute, r02 stamps), and a3 of tile T goes into T's first half-slot, which
+    // is dead by then (nrows * (W + 2) >= 128 pixels).
+    const int rrows = 2 * nrows;
+    const bool whole = (128 % (H * W)) == 0;             // tiles made of whole images keep the plain layout (no halo rows are read)
+    const int irows = whole ? hrows : rrows;             // rows of the a2 image
+    const int zero_px = irows * WP;
     int m0 = 0, g0 = 0;                          // first pixel / first image row of the current tile
+    int vrow0 = 0;                               // virtual row of halo row 0 of the current tile, mod 2*nrows
 
     float* s_sc1 = reinterpret_cast<float*>(smem);
     float* s_sh1 = s_sc1 + C;
@@ -128,9 +137,8 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     // ---- phase-A addressing (hoisted: the pipeline steps below must not spend VALU cycles on address arithmetic) ----
     // Tiles made of whole images never read their halo rows (every out-of-image tap is redirected to the zero pixels):
     // one pass over the tile's own 128 pixels (halo-pixel index W..W+127) is enough.
-    const bool whole = (128 % (H * W)) == 0;
-    const int hp0 = whole ? W : 0;
-    const int npass = whole ? 1 : ((hrows * W + 127) >> 7);
+    int hp0 = whole ? W : 0;                             // per tile (below): 2 W when the first two halo rows are in the ring already
+    int npass = whole ? 1 : ((hrows * W + 127) >> 7);
     const int xpx = tid >> 3, xcv = (tid & 7) * 8;       // this thread stages pixels xpx, xpx+64, channels xcv..+7
     int xo[2];                                           // element offsets of the two pixels in the pass being loaded
     bool xok[2];
@@ -268,11 +276,21 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         bneck_fold_tables<P>(a, s_sc1, tid, 512);
     }
 
-    for (int tile = bid_in; tile < ntiles; tile += nblk) {
+    // a block owns a CONTIGUOUS range of tiles (consecutive row groups of an image), so that the ring pays off
+    const int t_beg = (int)((long long)bid_in * ntiles / nblk), t_end = (int)((long long)(bid_in + 1) * ntiles / nblk);
+    (void)swz;
+    for (int tile = t_beg; tile < t_end; ++tile) {
     {
-        const int t = swz ? (tile & 7) * (ntiles >> 3) + (tile >> 3) : tile;   // tiles of one XCD are neighbours
-        m0 = t * 128;
+        m0 = tile * 128;
         g0 = m0 >> logW;
+        vrow0 = (tile * nrows) % rrows;
+        if (!whole) {
+            // halo rows 0 and 1 (= the previous tile's last two rows) are cached unless this is the block's first tile or the
+            // tile starts a new image (then row 0 is outside the image and row 1 was never computed)
+            const bool incr = tile > t_beg && (g0 % H) != 0;
+            hp0 = incr ? 2 * W : 0;
+            npass = incr ? 1 : ((hrows * W + 127) >> 7);
+        }
     }
     // first loads of the tile go out before anything else
     pass_addr(0);
@@ -284,9 +302,9 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     {
         constexpr int VR = LD2 / 8;
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int v = tid; v < (2 * hrows + 3) * VR; v += 512) {
+        for (int v = tid; v < (2 * irows + 3) * VR; v += 512) {
             const int pz = v / VR, cv = (v - pz * VR) * 8;
-            const int px = pz < 2 * hrows ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - 2 * hrows);
+            const int px = pz < 2 * irows ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - 2 * irows);
             *reinterpret_cast<uint4*>(sA2 + px * LD2 + cv) = z;
         }
     }
@@ -357,7 +375,8 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         const int hp = hp0 + 128 * p + q * 32 + (lane & 31);
         const int hr = hp >> logW, j = hp & (W - 1);
         if (hr < hrows) {
-            bf16_t* dst = sA2 + (hr * WP + j + 1) * LD2;
+            const int rr = whole ? hr : ((vrow0 + hr) & (rrows - 1));
+            bf16_t* dst = sA2 + (rr * WP + j + 1) * LD2;
 #pragma unroll
             for (int tn = 0; tn < TNH; ++tn)
 #pragma unroll
@@ -375,15 +394,18 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
 
     // =========================== phases B + C: 11-step weight-tile pipeline ===========================
     const int ml = q * 32 + (lane & 31);
+    const int a3px = whole ? 0 : vrow0 * WP;     // a3 overwrites this tile's first half-slot (its rows are dead after conv2)
     int ab[3];
     {
         const int ti = ml >> logW, tj = ml & (W - 1);
         const int g = g0 + ti;
         const int pr = g % H;
         const bool live = g < GR;
-        ab[0] = (live && pr - 1 >= 0) ? ((ti + 0) * WP + tj) * LD2 : zero_px * LD2;
-        ab[1] = live ? ((ti + 1) * WP + tj) * LD2 : zero_px * LD2;
-        ab[2] = (live && pr + 1 < H) ? ((ti + 2) * WP + tj) * LD2 : zero_px * LD2;
+        const int r0 = whole ? ti : ((vrow0 + ti) & (rrows - 1)), r1 = whole ? ti + 1 : ((vrow0 + ti + 1) & (rrows - 1)),
+                  r2 = whole ? ti + 2 : ((vrow0 + ti + 2) & (rrows - 1));
+        ab[0] = (live && pr - 1 >= 0) ? (r0 * WP + tj) * LD2 : zero_px * LD2;
+        ab[1] = live ? (r1 * WP + tj) * LD2 : zero_px * LD2;
+        ab[2] = (live && pr + 1 < H) ? (r2 * WP + tj) * LD2 : zero_px * LD2;
     }
     STAMP(2);
     // (the last barrier of phase A already separates its staging reads from the tile stores below)
@@ -442,7 +464,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
             for (int tn = 0; tn < TNH; ++tn)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) accC[s - 9][tn][i] = 0.f;
-            mma(sA2 + ml * LD2 + koff, s & 1, accC[s - 9]);          // a3 aliases a2: [128 px][LD2]
+            mma(sA2 + (a3px + ml) * LD2 + koff, s & 1, accC[s - 9]);          // a3 aliases the dead half of a2: [128 px][LD2]
         }
         if constexpr (s + 1 < NSTEP) {
             t_store(std::integral_constant<int, s + 1>{});
@@ -454,7 +476,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
         if constexpr (s == 8) {
             STAMP(4);
             // every wave is past its last a2 read: a3 = relu(bn3(conv2 + b2)) overwrites the image
-            bf16_t* dst = sA2 + ml * LD2;
+            bf16_t* dst = sA2 + (a3px + ml) * LD2;
 #pragma unroll
             for (int tn = 0; tn < TNH; ++tn)
 #pragma unroll
@@ -567,18 +589,20 @@ static int bneck_blocks(int tiles, int cap) {
 }
 
 template <int P>
-size_t bneck_lds_bytes(int W) {
+size_t bneck_lds_bytes(int H, int W) {
     constexpr int C = 2 * P, LD2 = P + 8, LDX = 72, CW = 32 * (P / 64);
     int logW = 0;
     while ((1 << logW) < W) ++logW;
-    const int hrows = (128 >> logW) + 2, WP = W + 2;
+    const int nrows = 128 >> logW, WP = W + 2;
+    const bool whole = (128 % (H * W)) == 0;
+    const int irows = whole ? nrows + 2 : 2 * nrows;          // a2 image: plain halo tile / ring of two half-slots
     const size_t r2 = std::max({(size_t)2 * P * LD2 * 2, (size_t)2 * (128 + P) * LDX * 2, (size_t)8 * 32 * (CW + 4) * 4});
-    return (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
+    return (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(irows * WP + 3) * LD2 * 2 + r2;
 }
 
 template <int P, bool DMA>
 int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
-    const size_t lds = std::max(bneck_lds_bytes<P>(a.W), bneck_lds_bytes<P>(b.W));
+    const size_t lds = std::max(bneck_lds_bytes<P>(a.H, a.W), bneck_lds_bytes<P>(b.H, b.W));
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P, DMA>),
@@ -603,10 +627,7 @@ int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st
 
 template <int P, bool DMA>
 int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
-    constexpr int C = 2 * P, LD2 = P + 8, LDX = 72, CW = 32 * (P / 64);
-    const int hrows = (128 >> logW) + 2, WP = a.W + 2;
-    const size_t r2 = std::max({(size_t)2 * P * LD2 * 2, (size_t)2 * (128 + P) * LDX * 2, (size_t)8 * 32 * (CW + 4) * 4});
-    const size_t lds = (size_t)(3 * C + 4 * P) * sizeof(float) + (size_t)(hrows * WP + 3) * LD2 * 2 + r2;
+    const size_t lds = bneck_lds_bytes<P>(a.H, a.W);
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_kernel<P, DMA>),

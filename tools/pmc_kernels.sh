@@ -19,7 +19,7 @@ for sub in ('bneck', 'conv'):
     for f in glob.glob('%s/%s/**/*counter_collection.csv' % (out, sub), recursive=True):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
-            if 'bneck_eval' in n or 'conv_tile' in n:
+            if 'bneck_eval' in n or 'conv_tile' in n or 'conv_pp' in n:
                 agg[(n, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
     for (n, g), c in sorted(agg.items()):
         m = {k: sum(v) / len(v) for k, v in c.items()}

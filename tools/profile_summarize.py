@@ -15,6 +15,7 @@ import shutil
 import sys
 
 out = sys.argv[1]
+PFX = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 STEPS = 26        # 1 eager + 5 warm-up + 20 timed steps in the --stats run
 
 
@@ -31,13 +32,13 @@ def trace(sub):
 
 # 1. stats
 for f in glob.glob('%s/stats/**/*kernel_stats.csv' % out, recursive=True):
-    shutil.copy(f, os.path.join(out, 'r02_kernel_stats.csv'))
+    shutil.copy(f, os.path.join(out, PFX + '_kernel_stats.csv'))
 dur = collections.defaultdict(list)
 for r in trace('stats'):
     grid = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
     wg = int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
     dur[(short(r['Kernel_Name']), str(grid), str(wg))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-with open(os.path.join(out, 'r02_per_shape.csv'), 'w', newline='') as f:
+with open(os.path.join(out, PFX + '_per_shape.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'grid_threads', 'workgroup', 'calls_per_step', 'avg_us', 'ms_per_step'])
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -56,7 +57,7 @@ def counters(sub, name):
 
 
 fe, wr = counters('step_FETCH_SIZE', 'FETCH_SIZE'), counters('step_WRITE_SIZE', 'WRITE_SIZE')
-with open(os.path.join(out, 'r02_hbm_traffic.csv'), 'w', newline='') as f:
+with open(os.path.join(out, PFX + '_hbm_traffic.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'grid_threads', 'launches_counted', 'FETCH_KB', 'WRITE_KB', 'hbm_MB_per_launch', 'avg_us', 'GB_per_s', 'frac_of_8TBs'])
     for k in sorted(set(fe) | set(wr), key=lambda k: -sum(fe.get(k, [0])) - sum(wr.get(k, [0]))):
@@ -75,7 +76,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     res[c] = sum(vals) / max(len(vals), 1)
     res[c + '_launches'] = len(vals)
 res['hbm_bytes_per_launch'] = (2.0 * res['FETCH_SIZE'] + res['WRITE_SIZE']) * 1024
-res['note'] = ('fused teacher Bottleneck N=32 64x64 C=256 P=128 (weight tiles by LDS-DMA); rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in '
+res['grid_cap'] = int(os.environ.get('FPD_BNECK_BLOCKS', '128'))       # the persistent grid the micro-benchmark launched (bench.py refuses a mismatch)
+res['note'] = ('fused teacher Bottleneck N=32 64x64 C=256 P=128 (weight tiles by LDS-DMA, conv1 rows kept in a ring), launched at the grid cap of the step; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in '
                'separate passes, mean over launches, KB -> bytes, read side doubled per the gfx950 calibration in MI355X_MICROARCH.md')
-json.dump(res, open(os.path.join(out, 'r02_pmc_bneck64.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(out, PFX + '_pmc_bneck64.json'), 'w'), indent=1)
 print(json.dumps(res))
