@@ -629,12 +629,17 @@ class FusedFPDStep:
         self.student.rng['adam'] = (b, len(self.student.plan))
         self._dist_work = None
 
-    def enable_metric(self):
-        """Per-iteration PCK of the last student map against the target, on the device (lib.core.evaluate.DeviceAccuracy)."""
-        if getattr(self, 'metric', None) is None:
+    def enable_metric(self, min_slots=0):
+        """Per-iteration PCK of the last student map against the target, on the device (lib.core.evaluate.DeviceAccuracy).
+        `min_slots`: the number of iterations the caller may leave between two drain() calls (the ring is sized to at
+        least that; an existing smaller ring is drained by the caller first and replaced)."""
+        m = getattr(self, 'metric', None)
+        if m is None or m.slots < min_slots:
+            assert m is None or m.pending() == 0, 'drain() the metric ring before enlarging it'
             from .lib.core.evaluate import DeviceAccuracy
             g, A = self.student.g, self.student.A
-            self.metric = DeviceAccuracy(self.B, self.J, self.hh, self.hw, self.dtype, self.student.state.device).bind(
+            self.metric = DeviceAccuracy(self.B, self.J, self.hh, self.hw, self.dtype, self.student.state.device,
+                                         slots=max(4096, int(min_slots))).bind(
                 A.ptr(g.outputs[-1].buf), A.tensor('target').data_ptr(), A.tensor('losses').data_ptr())
         return self.metric
 
@@ -732,9 +737,13 @@ class FusedFPDStep:
         out = []
         for b, (lo, hi) in enumerate(table.buckets):
             op = s.bucket_ops.get(b)
-            if op is None or hi <= lo:
+            if hi <= lo:
                 continue
+            assert op is not None, 'gradient bucket %d [%d, %d) has no completion op: it would never be all-reduced' % (b, lo, hi)
             out.append((lo, hi, (lambda stream, op=op: s.plan.wait_op(op, C.c_void_p(stream.cuda_stream)))))
+        cover = sorted((lo, hi) for lo, hi, _ in out)
+        assert cover and cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), \
+            'gradient buckets %r do not tile the arena [0, %d)' % (cover, n)
         return out
 
     def enable_graphs(self):

@@ -36,9 +36,6 @@ class AverageMeter(object):
         self.avg = self.sum / self.count if self.count != 0 else 0
 
 
-_STEPS = {}
-
-
 def _unwrap(m):
     return m.module if hasattr(m, 'module') else m
 
@@ -59,16 +56,22 @@ def fused_step_for(model, tmodel, optimizer, batch_shape, alpha, world_size=1, u
     """One FusedFPDStep per (student, teacher, batch shape); shares Adam state with the FusedAdam optimizer.
     tmodel None = plain (non-distillation) training: no teacher graph, alpha must be 0."""
     s, t = _unwrap(model), (_unwrap(tmodel) if tmodel is not None else None)
-    key = (id(s), id(t), id(optimizer), tuple(batch_shape), float(alpha), world_size, tuple(use_target_weight))
-    if key not in _STEPS:
-        n, _, h, w = batch_shape
-        assert t is not None or alpha == 0.0
-        step = E.FusedFPDStep(s.device_state(), s.cfg_hg, t.device_state() if t is not None else None,
-                              t.cfg_hg if t is not None else None, n, h, w, alpha,
-                              lr=float(optimizer.param_groups[0]['lr']), world_size=world_size,
-                              adam=optimizer, use_target_weight=use_target_weight)
-        _STEPS[key] = step
-    return _STEPS[key]
+    # The cache lives ON the student module (not in a module-level dict keyed by id(): ids are recycled once an object
+    # is collected, and a global would keep every plan and its arenas alive for the life of the process).  The teacher
+    # and optimizer are compared by identity through the references the entry holds, so they cannot be recycled either.
+    cache = s.__dict__.setdefault('_fused_steps', {})
+    key = (tuple(batch_shape), float(alpha), world_size, tuple(use_target_weight))
+    hit = cache.get(key)
+    if hit is not None and hit[0] is t and hit[1] is optimizer:
+        return hit[2]
+    n, _, h, w = batch_shape
+    assert t is not None or alpha == 0.0
+    step = E.FusedFPDStep(s.device_state(), s.cfg_hg, t.device_state() if t is not None else None,
+                          t.cfg_hg if t is not None else None, n, h, w, alpha,
+                          lr=float(optimizer.param_groups[0]['lr']), world_size=world_size,
+                          adam=optimizer, use_target_weight=use_target_weight)
+    cache[key] = (t, optimizer, step)
+    return step
 
 
 def _run_epoch(config, train_loader, model, tmodel, use_w, optimizer, epoch, writer_dict, allreduce, world_size, alpha):
@@ -102,7 +105,7 @@ def _run_epoch(config, train_loader, model, tmodel, use_w, optimizer, epoch, wri
                 step.flush()
                 drain()
             step = fused_step_for(model, tmodel, optimizer, inp.shape, alpha, world_size, use_w)
-            metric = step.enable_metric()              # PCK + losses of every iteration, logged on the device
+            metric = step.enable_metric(min_slots=config.PRINT_FREQ + 1)   # PCK + losses of every iteration, logged on the device
             metric.drain()
             n_img = inp.size(0)
             step.teacher_async(inp)                    # pipeline prologue: teacher forward of the first batch

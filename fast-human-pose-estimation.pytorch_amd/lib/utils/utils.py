@@ -75,21 +75,24 @@ class FusedAdam(torch.optim.Optimizer):
         return {'state': state, 'param_groups': [g]}
 
     def load_state_dict(self, sd):
-        if 'm' in sd and 'v' in sd:                      # round-1 flat layout
-            self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_dev.copy_(sd['step'])
-        else:
-            st = sd.get('state', {})
-            mv, vv = self._views(self.m), self._views(self.v)
-            if len(st) not in (0, len(mv)):
-                raise ValueError('optimizer state has %d parameter entries, the model has %d' % (len(st), len(mv)))
-            self.m.zero_(); self.v.zero_(); self.step_dev.zero_()
-            ids = sd['param_groups'][0]['params']
-            for dst_m, dst_v, pid in zip(mv, vv, ids):
-                e = st.get(pid)
-                if e is None:
-                    continue
-                dst_m.copy_(e['exp_avg']); dst_v.copy_(e['exp_avg_sq'])
-                self.step_dev.fill_(int(float(e['step'])))
+        if 'm' in sd and 'v' in sd:
+            # the round-1 checkpoints held the two moment arenas as flat tensors in the parameter order of THAT round; the
+            # table has been re-ordered since (backward-completion buckets), so copying them would hand every parameter
+            # another parameter's moments.  Refuse instead of mis-assigning.
+            raise ValueError('optimizer state in the retired flat {m, v, step} layout cannot be mapped onto the current '
+                             'parameter order; resume from a torch.optim.Adam-style state_dict (state / param_groups)')
+        st = sd.get('state', {})
+        mv, vv = self._views(self.m), self._views(self.v)
+        if len(st) not in (0, len(mv)):
+            raise ValueError('optimizer state has %d parameter entries, the model has %d' % (len(st), len(mv)))
+        self.m.zero_(); self.v.zero_(); self.step_dev.zero_()
+        ids = sd['param_groups'][0]['params']
+        for dst_m, dst_v, pid in zip(mv, vv, ids):
+            e = st.get(pid)
+            if e is None:
+                continue
+            dst_m.copy_(e['exp_avg']); dst_v.copy_(e['exp_avg_sq'])
+            self.step_dev.fill_(int(float(e['step'])))
         g = sd['param_groups'][0]
         for k in ('lr', 'betas', 'eps', 'initial_lr'):   # initial_lr: what torch's LR schedulers resume from
             if k in g:

@@ -233,6 +233,9 @@ def test_fused_adam_state_dict_interoperates_with_torch_adam_and_resumes():
     assert opt2.param_groups[0]['initial_lr'] == 1e-3
     # a fresh optimizer's state dict has no per-parameter state, like torch's
     assert FusedAdam(m, lr=1e-3).state_dict()['state'] == {}
+    # the retired round-1 flat {m, v, step} checkpoints cannot be mapped onto the re-ordered arena: refused, not mis-assigned
+    with pytest.raises(ValueError, match='flat'):
+        opt2.load_state_dict({'m': opt.m.clone(), 'v': opt.v.clone(), 'step': torch.tensor(2), 'param_groups': sd['param_groups']})
     # schedule: reference = MultiStepLR(milestones, gamma, last_epoch=-1) stepped at the start of every epoch
     import warnings
     o = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2.5e-4)

@@ -165,6 +165,9 @@ def main():
             save_checkpoint({'epoch': epoch + 1, 'model': cfg.MODEL.NAME, 'state_dict': model.state_dict(),
                              'best_state_dict': model.module.state_dict(), 'perf': perf_indicator,
                              'optimizer': optimizer.state_dict()}, best_model, out_dir)
+        if world > 1:
+            dist.barrier()       # ranks != 0 wait for rank 0's validation + checkpoint HERE, explicitly, rather than inside
+                                 # the first gradient all-reduce of the next epoch
     if rank == 0:
         torch.save(model.module.state_dict(), os.path.join(out_dir, 'final_state.pth'))      # :288-294
     if world > 1:
