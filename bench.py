@@ -98,6 +98,108 @@ def cpu_baseline():
             'thread_sweep_cfg1_images_per_s': sweep, 'variants': variants}
 
 
+def hr_extra(widths):
+    """MODEL.EXTRA of experiments/fpd_coco/hrnet/*.yaml for the given branch widths (W32: 32..256, W48: 48..384)."""
+    st = lambda n, m: dict(NUM_MODULES=m, NUM_BRANCHES=n, BLOCK='BASIC', NUM_BLOCKS=[4] * n, NUM_CHANNELS=widths[:n], FUSE_METHOD='SUM')
+    return {'FINAL_CONV_KERNEL': 1, 'PRETRAINED_LAYERS': ['*'], 'STAGE2': st(2, 1), 'STAGE3': st(3, 4), 'STAGE4': st(4, 3)}
+
+
+def cpu_baseline_hrnet():
+    """The same loop of the CPU oracle (function.py:114-147) over the HRNet restatement (oracle/hrnet_ref.py): W32 student,
+    W48 teacher, 256x192, J=17 at batch 2 -- 3 timed steps after one warm-up, teacher under no_grad and reference-faithful."""
+    from oracle import fpd_ref, hrnet_ref
+    ncpu = os.cpu_count() or 1
+    ex_s, ex_t = hr_extra([32, 64, 128, 256]), hr_extra([48, 96, 192, 384])
+    fs = lambda sd, x, train: [hrnet_ref.hrnet_forward(sd, ex_s, x, train)]
+    ft = lambda sd, x, train: [hrnet_ref.hrnet_forward(sd, ex_t, x, train)]
+    B = 2
+    x, tg, tw = fpd_ref.synth_batch(100, B, 17, image_size=(192, 256), heatmap_size=(48, 64))
+
+    def t_step(steps, no_grad):
+        torch.manual_seed(0)
+        s_sd = fpd_ref.synth_state_dict(hrnet_ref.hrnet_keys(ex_s, 17), 1)
+        t_sd = fpd_ref.synth_state_dict(hrnet_ref.hrnet_keys(ex_t, 17), 2)
+        adam = {}
+        kw = dict(adam_state=adam, teacher_no_grad=no_grad, student_forward=fs, teacher_forward=ft)
+        fpd_ref.fpd_step(s_sd, t_sd, 1, 1, x, tg, tw, 0.5, **kw)
+        t0 = time.time()
+        for _ in range(steps):
+            fpd_ref.fpd_step(s_sd, t_sd, 1, 1, x, tg, tw, 0.5, **kw)
+        return (time.time() - t0) / steps
+    t_begin = time.time()
+    sweep = {}
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32)}):
+        torch.set_num_threads(nt)
+        sweep[nt] = round(B / t_step(1, True), 3)
+        if time.time() - t_begin > 30:
+            break
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    variants = []
+    for no_grad in (True, False):
+        dt = t_step(3, no_grad)
+        variants.append({'config': 'configs[3] shapes W32 <- W48 256x192', 'batch': B, 'timed_steps': 3, 's_per_step': round(dt, 3),
+                         'teacher': 'no_grad' if no_grad else 'graph retained (reference-faithful)', 'images_per_s': round(B / dt, 3)})
+    return {'value': variants[0]['images_per_s'], 'unit': 'images/s', 'cores': best, 'kind': 'port',
+            'sample': 'same HRNet pair (W32 <- W48, 256x192, J=17) at batch %d, 3 timed steps after 1 warm-up, torch CPU fp32 oracle '
+                      '(oracle/hrnet_ref.py), teacher under no_grad, %d threads (best of the sweep on %d host CPUs)' % (B, best, ncpu),
+            'thread_sweep_images_per_s': sweep, 'variants': variants}
+
+
+def time_plan_op(R, plan, k, launches):
+    """Mean device time (us) of plan op `k` re-issued back to back on the current stream between two HIP events."""
+    l, st = R.lib(), R.current_stream()
+    for _ in range(2):
+        plan.run_op(k)
+    e0, e1 = l.fpd_event_create(), l.fpd_event_create()
+    l.fpd_event_record(e0, st)
+    for _ in range(launches):
+        plan.run_op(k)
+    l.fpd_event_record(e1, st)
+    return l.fpd_event_elapsed_ms(e0, e1) / launches * 1e3
+
+
+def conv_classes(step, R, peak_tflops, launches=12, top=6):
+    """Every (role, kind, shape) class of convolution launch of the step -- student forward / data gradient / weight
+    gradient, teacher forward -- with its launch count, one recorded representative timed live (the op of the step's own
+    plan, same arguments, grid and slabs), and its roofline: algorithmic FLOPs and bytes (operand in + result out, bf16),
+    bound = whichever of the HBM (8 TB/s) and MFMA limits is the longer time.  Sorted by launches x time."""
+    groups = {}
+    for role, inst in (('student', step.student),) + tuple(('teacher', t) for t in step.teachers[:1]):
+        g = inst.g
+        for phase, ops in (('fwd', g.fwd), ('bwd', g.bwd if inst.train else [])):
+            for o in ops:
+                if o.kind not in ('conv', 'wgrad'):
+                    continue
+                k = inst.op_index.get(id(o))
+                if k is None or inst.plan.op_type(k) == R.OP_NOP:
+                    continue
+                kind = 'weight gradient' if o.kind == 'wgrad' else ('data gradient' if phase == 'bwd' else 'forward')
+                e = groups.setdefault((role, kind, tuple(o.dims)), [inst.plan, k, 0, o])
+                e[2] += 1
+    out = []
+    for (role, kind, dims), (plan, k, count, o) in groups.items():
+        n, h, w, C, K, Rr, S, stride, pad, P, Q = dims
+        flops = 2.0 * n * P * Q * C * K * Rr * S
+        nbytes = 2.0 * (n * h * w * C + n * P * Q * K)
+        if o.kind == 'conv' and getattr(o, 'residual', None) is not None:
+            nbytes += 2.0 * n * P * Q * K
+        out.append({'role': role, 'kind': kind, 'conv': '%dx%d %d->%d stride %d on %dx%dx%d' % (Rr, S, C, K, stride, n, h, w),
+                    'launches_per_step': count, 'flops': flops, 'bytes': nbytes, '_plan': plan, '_k': k})
+    # time the classes that can matter (largest algorithmic cost first; a class whose roofline time is tiny can still be slow,
+    # so the cut is generous)
+    for e in out:
+        e['us'] = time_plan_op(R, e.pop('_plan'), e.pop('_k'), launches)
+        t_hbm, t_mfma = e['bytes'] / 8e12 * 1e6, e['flops'] / (peak_tflops * 1e12) * 1e6
+        e['bound'] = 'hbm' if t_hbm >= t_mfma else 'mfma'
+        e['roofline_us'] = round(max(t_hbm, t_mfma), 2)
+        e['frac'] = round(max(t_hbm, t_mfma) / e['us'], 4)
+        e['ms_per_step'] = round(e['us'] * e['launches_per_step'] * 1e-3, 3)
+        e['us'] = round(e['us'], 2)
+    out.sort(key=lambda e: -e['ms_per_step'])
+    return out[:top], round(sum(e['ms_per_step'] for e in out), 3)
+
+
 def dominant_kernel(step, R, launches=50):
     """Live timing of the dominant (kernel, shape): the teacher's first 64x64 fused Bottleneck, re-launched `launches`
     times back to back on the current stream between two HIP events.  Returns None if the teacher graph is unfused."""
@@ -127,7 +229,7 @@ def dominant_kernel(step, R, launches=50):
             'per_step': (n_single, n_paired), 'grid_cap': int(os.environ.get('FPD_BNECK_BLOCKS', '128'))}
 
 
-def parity_object(hourglass, E, synth, student, teacher, batch, dev, J, H, W):
+def parity_object(build_pair, E, student, teacher, batch, dev, H, W):
     """Accuracy of the build that was just timed (bf16), measured here on the bench batch against the fp32 parity build of
     the same path (the build pinned to the reference within 1e-4 by tests/test_model_gpu.py / test_fullsize_gpu.py): same
     initial student weights, same calibrated teacher, one un-pipelined FPD iteration each.  The reference-relative
@@ -138,8 +240,7 @@ def parity_object(hourglass, E, synth, student, teacher, batch, dev, J, H, W):
 
     def one(dtype):
         torch.manual_seed(1)
-        s = hourglass.get_pose_net(make_cfg(128, 4, J, dtype), is_train=True)
-        t = hourglass.get_pose_net(make_cfg(256, 8, J, dtype), is_train=False)
+        s, t = build_pair(dtype)
         s.load_state_dict(student, strict=True)
         t.load_state_dict(teacher, strict=True)
         s, t = s.to(dev), t.to(dev)
@@ -150,7 +251,7 @@ def parity_object(hourglass, E, synth, student, teacher, batch, dev, J, H, W):
         torch.cuda.current_stream().wait_event(st.ev_t[0])
         g.run('prep'); g.run('fwd'); g.run('mid'); g.run('bwd')
         torch.cuda.synchronize()
-        out = {'tmap': st.tmap[0].float().cpu(), 'map': g.output_view(3).float().cpu(), 'loss': st.losses(),
+        out = {'tmap': st.tmap[0].float().cpu(), 'map': g.output_view(len(g.g.outputs) - 1).float().cpu(), 'loss': st.losses(),
                'grad': s.device_state().A.tensor('grad').float().cpu().clone()}
         del st, s, t
         torch.cuda.empty_cache()
@@ -274,20 +375,23 @@ def main():
         from fpd_amd.lib.config import _wrap
         from fpd_amd.lib.models import pose_hrnet
 
-        def hr_cfg(w, weight_dtype=''):
-            st = lambda n, m: dict(NUM_MODULES=m, NUM_BRANCHES=n, BLOCK='BASIC', NUM_BLOCKS=[4] * n, NUM_CHANNELS=w[:n], FUSE_METHOD='SUM')
-            return _wrap({'MODEL': {'NAME': 'pose_hrnet', 'NUM_JOINTS': J, 'INIT_WEIGHTS': False, 'PRETRAINED': '', 'DTYPE': args.dtype,
-                                    'WEIGHT_DTYPE': weight_dtype,
-                                    'EXTRA': {'FINAL_CONV_KERNEL': 1, 'PRETRAINED_LAYERS': ['*'], 'STAGE2': st(2, 1), 'STAGE3': st(3, 4),
-                                              'STAGE4': st(4, 3)}}})
-        student = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256], 'fp8' if (f8 and not args.no_fp8) else ''), is_train=True).to(dev)
-        torch.manual_seed(2)
-        teacher = pose_hrnet.get_pose_net(hr_cfg([48, 96, 192, 384]), is_train=False).to(dev)
-        args.no_parity = args.no_cpu_baseline = True
+        def hr_cfg(w, dtype, weight_dtype=''):
+            return _wrap({'MODEL': {'NAME': 'pose_hrnet', 'NUM_JOINTS': J, 'INIT_WEIGHTS': False, 'PRETRAINED': '', 'DTYPE': dtype,
+                                    'WEIGHT_DTYPE': weight_dtype, 'EXTRA': hr_extra(w)}})
+
+        def build_pair(dtype):
+            s_ = pose_hrnet.get_pose_net(hr_cfg([32, 64, 128, 256], dtype, 'fp8' if (f8 and not args.no_fp8 and dtype == 'bf16') else ''), is_train=True)
+            torch.manual_seed(2)
+            return s_, pose_hrnet.get_pose_net(hr_cfg([48, 96, 192, 384], dtype), is_train=False)
+        if f8:                                   # secondary line (parked path, README): step-level roofline only
+            args.no_parity = args.no_cpu_baseline = True
     else:
-        student = hourglass.get_pose_net(make_cfg(128, 4, J, args.dtype), is_train=True).to(dev)
-        torch.manual_seed(2)
-        teacher = hourglass.get_pose_net(make_cfg(256, 8, J, args.dtype), is_train=False).to(dev)
+        def build_pair(dtype):
+            s_ = hourglass.get_pose_net(make_cfg(128, 4, J, dtype), is_train=True)
+            torch.manual_seed(2)
+            return s_, hourglass.get_pose_net(make_cfg(256, 8, J, dtype), is_train=False)
+    student, teacher = build_pair(args.dtype)
+    student, teacher = student.to(dev), teacher.to(dev)
 
     # synthetic teacher: calibrate BN running statistics once so eval-mode activations are sane
     x, tg, tw = synth.make_batch(1000 + rank, B, J, (W, H), (W // 4, H // 4))
@@ -330,11 +434,17 @@ def main():
     l.fpd_event_record(ev0, st)
     step.run_pipelined(args.steps, allreduce)      # K teacher forwards + K student steps, pipeline starts/ends empty
     l.fpd_event_record(ev1, st)
-    host_enqueue_ms = (time.time() - t0) / args.steps * 1e3      # nothing in there synchronises: pure launch-path time
+    host_busy_ms = (time.time() - t0) / args.steps * 1e3         # host time inside the timed region (includes back-pressure of full queues)
     barrier()
     wall = time.time() - t0
     ev_ms = l.fpd_event_elapsed_ms(ev0, ev1)
     pose, kd, loss = step.losses()
+    # host launch path, measured where nothing can block it: ONE step enqueued into empty queues after the timed region
+    # (every kernel launch, event record / wait of one teacher forward + one student step), clock stopped before any sync
+    t1 = time.time()
+    step.run_pipelined(1, allreduce)
+    host_enqueue_ms = (time.time() - t1) * 1e3
+    barrier()
     if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,6 +460,13 @@ def main():
                          'GFLOP/image x %d), HIP events on the launch stream: %.3f ms/step' % (flop_step / 1e12, gfl, B,
                                                                                               ev_ms / args.steps)}
     dom = dominant_kernel(step, R) if (rank == 0 and args.dtype == 'bf16' and not hr) else None
+    classes = None
+    if rank == 0 and args.dtype == 'bf16' and not args.graphs:
+        top, total_ms = conv_classes(step, R, peak)
+        classes = {'top': top, 'all_classes_ms_per_step_serialised': total_ms,
+                   'note': 'un-paired convolution launches of the step by (role, kind, shape): one recorded op of the step\'s own '
+                           'plan per class re-issued 12x back to back between HIP events after the timed region; frac = roofline '
+                           'time (max of algorithmic bytes / 8 TB/s and FLOPs / dense MFMA peak) / measured time'}
     if dom is not None:
         # HBM bytes/launch from separate rocprofv3 --pmc passes (tools/pmc_bneck.sh), only if that file was measured at the
         # launch geometry timed here (grid cap): a file from another geometry is refused, not quoted
@@ -375,9 +492,25 @@ def main():
                             'events on the launch stream after the timed region; traffic = HBM bytes/launch from rocprofv3 --pmc '
                             'passes at the same grid cap (profiles/), null if absent' % dom['launches'],
                     'step': step_roof}
+    elif classes is not None and classes['top']:
+        # no fused-Bottleneck teacher here (HRNet): the dominant (kernel, shape) is the costliest convolution class of the step
+        d = classes['top'][0]
+        if d['bound'] == 'hbm':
+            ach, pk, unit = d['bytes'] / (d['us'] * 1e-6) / 1e9, 8000.0, 'GB/s'
+        else:
+            ach, pk, unit = d['flops'] / (d['us'] * 1e-6) / 1e12, peak, 'TFLOP/s'
+        roofline = {'bound': d['bound'], 'achieved': round(ach, 2), 'peak': pk, 'unit': unit, 'frac': round(ach / pk, 4),
+                    'traffic': None, 'traffic_source': 'no PMC pass for this kernel yet (profiles/README.md)',
+                    'kernel': '%s %s, %s' % (d['role'], d['kind'], d['conv']), 'avg_us': d['us'],
+                    'flop_per_launch': d['flops'], 'algorithmic_bytes_per_launch': d['bytes'],
+                    'launches_per_step': d['launches_per_step'],
+                    'note': 'the convolution class with the largest launches x time of the step (conv_classes below), timed as '
+                            'recorded in the step plan; bound chosen by which roofline time is longer', 'step': step_roof}
     else:
         roofline = {'bound': 'mfma', 'achieved': step_roof['achieved'], 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': step_roof['frac'], 'traffic': None, 'note': step_roof['note']}
+    if classes is not None:
+        roofline['conv_classes'] = classes
     out = {
         'metric': ('images/sec FPD train step (HRNet-W32 student with fp8 forward convolutions, HRNet-W48 teacher) 384x288' if f8 else
                    'images/sec FPD train step (HRNet-W32 student, HRNet-W48 teacher) 256x192' if hr else
@@ -395,6 +528,7 @@ def main():
                    'global_batch': world * B, 'parallelism': 'dp%d' % world, 'backend': args.backend,
                    'launch': 'hipGraph replay per phase' if args.graphs else 'one native plan call per phase, kernels launched eagerly on 3 streams',
                    'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+                   'host_ms_per_step_inside_timed_region': round(host_busy_ms, 3),
                    'launches_per_step': step.launches_per_step(),
                    'ranks': world,
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
@@ -411,10 +545,10 @@ def main():
     if init_sd is not None:
         del step
         torch.cuda.empty_cache()
-        out['parity'] = parity_object(hourglass, E, synth, init_sd[0], init_sd[1], (x, tg, tw), dev, J, H, W)
+        out['parity'] = parity_object(build_pair, E, init_sd[0], init_sd[1], (x, tg, tw), dev, H, W)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t_cpu = time.time()
-        out['cpu_baseline'] = cpu_baseline()
+        out['cpu_baseline'] = cpu_baseline_hrnet() if hr else cpu_baseline()
         print('[bench] cpu baseline took %.1f s' % (time.time() - t_cpu), file=sys.stderr, flush=True)
     if rank == 0:
         print(json.dumps(out), flush=True)

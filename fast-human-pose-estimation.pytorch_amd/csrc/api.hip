@@ -638,6 +638,11 @@ int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     return rc;
 }
 
+int fpd_plan_run_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
+    FPD_REQUIRE(p && op >= 0 && op < (int)p->ops.size(), "plan_run_op: bad op index %d", op);
+    return run_op(p->ops[op], stream);
+}
+
 int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     FPD_REQUIRE(p, "plan_capture: null");
     hipStream_t st = (hipStream_t)stream;

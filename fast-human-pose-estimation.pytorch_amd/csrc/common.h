@@ -96,6 +96,46 @@ __device__ __forceinline__ void bn_coef(const fpd_bn_t& bn, int c, int C, double
     shift = (float)((double)bn.beta[c] - m * g * is);
 }
 
+// The same coefficients in two halves, for prologues that want every load in flight before any of the fp64 arithmetic:
+// bn_request() only issues the loads of channel c, bn_resolve() does the arithmetic of bn_coef() on what arrived.
+struct BnRaw { double s[2 * FPD_STATS_REPLICAS]; float g, b, eps; int mode; };
+__device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnRaw& r) {
+    r.mode = bn.mode; r.eps = bn.eps;
+#pragma unroll
+    for (int q = 0; q < 2 * FPD_STATS_REPLICAS; ++q) r.s[q] = 0.0;
+    r.g = 1.f; r.b = 0.f;
+    if (bn.mode == FPD_BN_NONE) return;
+    if (bn.mode == FPD_BN_TRAIN) {
+#pragma unroll
+        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { r.s[2 * q] = bn.stats[q * 2 * C + c]; r.s[2 * q + 1] = bn.stats[q * 2 * C + C + c]; }
+    } else {
+        r.s[0] = (double)bn.running_mean[c];
+        r.s[1] = (double)bn.running_var[c];
+    }
+    r.g = bn.gamma[c];
+    r.b = bn.beta[c];
+}
+__device__ __forceinline__ void bn_resolve(const BnRaw& r, double count, float& scale, float& shift, float& mean, float& invstd) {
+    double m, var;
+    if (r.mode == FPD_BN_TRAIN) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += r.s[2 * q]; s2 += r.s[2 * q + 1]; }   // same order as bn_coef()
+        m = s1 / count;
+        var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+    } else {
+        m = r.s[0];
+        var = r.s[1];
+    }
+    const double is = 1.0 / sqrt(var + (double)r.eps);
+    const double g = (double)r.g;
+    mean = (float)m;
+    invstd = (float)is;
+    scale = (float)(g * is);
+    shift = (float)((double)r.b - m * g * is);
+}
+
 // Fill LDS scale/shift tables for all C channels (call from every thread, then __syncthreads()).
 __device__ __forceinline__ void bn_fill(const fpd_bn_t& bn, int C, double count, float* s_scale, float* s_shift) {
     if (bn.mode == FPD_BN_NONE) return;

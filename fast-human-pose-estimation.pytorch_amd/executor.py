@@ -472,8 +472,9 @@ class GraphInstance:
                     p.add(*self.low.op(G.Op('head_fold', target=sub)))
         self.rng['prep'] = (b, len(p))
         b = len(p)
+        self.op_index = {}                         # id(IR op) -> plan op (bench.py times single recorded ops through it)
         for op in g.fwd:
-            p.add(*self.low.op(op))
+            self.op_index[id(op)] = p.add(*self.low.op(op))
         self.rng['fwd'] = (b, len(p))
         self._schedule('fwd', list(g.fwd))
         b = len(p)
@@ -489,7 +490,7 @@ class GraphInstance:
             self.low.finish_partials()                # patches the wgrad structs / fills the per-bucket reduce tables
             self.bucket_ops = {}                      # gradient bucket -> plan op after which its grad slice is final
             for ir, (code, st) in zip(bwd_ir, lowered):
-                k = p.add(code, st)
+                k = self.op_index[id(ir)] = p.add(code, st)
                 if ir.kind == 'grad_ready':
                     self.bucket_ops[ir.bucket] = k
                     p.mark_event(k)

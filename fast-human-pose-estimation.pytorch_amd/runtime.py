@@ -216,6 +216,7 @@ SYMBOLS = {
     'fpd_plan_mark_event': (C.c_int, [_vp, _i32]),
     'fpd_plan_wait_op': (C.c_int, [_vp, _i32, _vp]),
     'fpd_plan_run': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'fpd_plan_run_op': (C.c_int, [_vp, _i32, _vp]),
     'fpd_plan_capture': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpd_plan_replay': (C.c_int, [_vp, _i32, _vp]),
     'fpd_last_error': (C.c_char_p, []),
@@ -323,6 +324,10 @@ class Plan:
     def run(self, begin, end, stream=None):
         check(self._l.fpd_plan_run(self._p, begin, end, stream if stream is not None else current_stream()),
               'fpd_plan_run')
+
+    def run_op(self, op, stream=None):
+        """One recorded op on `stream` itself (lane and waits ignored) -- for timing a kernel exactly as the step launches it."""
+        check(self._l.fpd_plan_run_op(self._p, op, stream if stream is not None else current_stream()), 'fpd_plan_run_op')
 
     def capture(self, begin, end, stream):
         gid = self._l.fpd_plan_capture(self._p, begin, end, stream)

@@ -483,6 +483,9 @@ int fpd_plan_mark_event(fpd_plan* p, int32_t op);
 int fpd_plan_wait_op(fpd_plan* p, int32_t op, fpd_stream_t stream);
 /* launch ops [begin,end) on stream (and the plan's side-lane streams, see above) */
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
+/* Issue the single op `op` on `stream` itself, ignoring its lane and waits (measurement aid: bench.py re-launches one
+ * recorded op back to back between two events to time a kernel exactly as the step launches it). */
+int fpd_plan_run_op(fpd_plan* p, int32_t op, fpd_stream_t stream);
 /* capture ops [begin,end) into a hipGraph once, then replay it (graph id returned by capture) */
 int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream);
 int fpd_plan_replay(fpd_plan* p, int32_t graph_id, fpd_stream_t stream);

@@ -61,26 +61,31 @@ def param_names(sd):
 
 
 def fpd_step(student_sd, teacher_sd, s_stacks, t_stacks, inp, target, target_weight, alpha,
-             adam_state=None, lr=2.5e-4, teacher_no_grad=True):
+             adam_state=None, lr=2.5e-4, teacher_no_grad=True, student_forward=None, teacher_forward=None):
     """One iteration of function.py:114-147 on CPU.  Mutates student_sd (Adam update and BN
     running stats) in place.  Returns dict(outputs, toutput, pose, kd, loss, grads).
 
     teacher_no_grad=False reproduces the reference faithfully (the teacher forward is NOT under
     no_grad, function.py:120, so autograd also back-propagates through the teacher); the student
-    gradients are identical either way."""
+    gradients are identical either way.
+
+    student_forward / teacher_forward: optional callables (sd, x, train) -> [maps] replacing the hourglass forward (the
+    same loop drives any pose net of the reference: bench.py passes the HRNet restatement for its configs[3] line)."""
+    fwd_s = student_forward or (lambda sd, x, train: hourglass_ref.hourglass_forward(sd, x, s_stacks, train=train))
+    fwd_t = teacher_forward or (lambda sd, x, train: hourglass_ref.hourglass_forward(sd, x, t_stacks, train=train))
     names = param_names(student_sd)
     for k in names:
         student_sd[k].requires_grad_(True)
         student_sd[k].grad = None
-    outputs = hourglass_ref.hourglass_forward(student_sd, inp, s_stacks, train=True)
+    outputs = fwd_s(student_sd, inp, True)
     if teacher_no_grad:
         with torch.no_grad():
-            toutput = hourglass_ref.hourglass_forward(teacher_sd, inp, t_stacks, train=False)[-1]
+            toutput = fwd_t(teacher_sd, inp, False)[-1]
     else:
         tn = param_names(teacher_sd)
         for k in tn:
             teacher_sd[k].requires_grad_(True)
-        toutput = hourglass_ref.hourglass_forward(teacher_sd, inp, t_stacks, train=False)[-1]
+        toutput = fwd_t(teacher_sd, inp, False)[-1]
     pose, kd, loss = fpd_losses(outputs, toutput, target, target_weight, alpha)
     loss.backward()
     grads = {k: student_sd[k].grad.detach().clone() for k in names}
