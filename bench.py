@@ -538,8 +538,12 @@ def main():
         out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
         exp = getattr(allreduce, 'exposed_us', None)
         out['config']['allreduce_exposed_us'] = round(exp(), 1) if exp else None
-        out['config']['allreduce'] = 'one asynchronous RCCL all-reduce per gradient bucket (%d buckets, %d fp32 elements in total), waited for before Adam' % (
-            len(student.table.buckets), student.table.sizes['param'])
+        bucketed = os.environ.get('FPD_ALLREDUCE_BUCKETS', '0') == '1'
+        out['config']['allreduce'] = ('one asynchronous RCCL all-reduce per gradient bucket from a side stream (%d buckets, %d fp32 elements in total), waited for before Adam' % (
+            len(student.table.buckets), student.table.sizes['param']) if bucketed else
+            'ONE asynchronous RCCL all-reduce of the flat gradient arena (%d fp32 elements) issued behind the backward, waited for before Adam '
+            '(overlaps the next teacher forward); FPD_ALLREDUCE_BUCKETS=1 = one per bucket' % student.table.sizes['param'])
+        out['config']['gpu_max_hw_queues'] = os.environ.get('GPU_MAX_HW_QUEUES')
     if rank == 0:
         print('[bench] timed region done: %.3f ms/step; parity / cpu baseline next' % ms_per_step, file=sys.stderr, flush=True)
     if init_sd is not None:

@@ -7,11 +7,21 @@ per-replica BatchNorm statistics (the same semantics DataParallel has), the loss
 1/world so the summed gradient is the gradient of the global-batch mean (equal shards).  The collective is
 issued asynchronously right after the backward and waited for only before Adam, i.e. it overlaps the NEXT
 step's teacher forward, which does not depend on the student weights (executor.FusedFPDStep.step)."""
+import os
+
 import torch
 
 
 def make_allreduce(dist, group=None):
     """Returns hook(flat_grad, buckets=None) -> wait() for executor.FusedFPDStep.student_step(allreduce=...).
+
+    Default: ONE all-reduce of the whole arena, issued behind the backward on the student's stream and waited for right
+    before Adam -- it overlaps the next step's teacher forward, and no stream beyond RCCL's own is created.
+    FPD_ALLREDUCE_BUCKETS=1 (opt-in): one collective per gradient bucket from a side stream, so the early buckets'
+    collectives also overlap the rest of the backward.  It is NOT the default because of a measured pathology of this
+    ROCm stack (profiles/README.md, round 3): the side stream is the sixth active hardware queue of the process, and with
+    GPU_MAX_HW_QUEUES=8 (what the three hot streams need so that they never share a queue) the step then takes 26.7 ms
+    instead of 10.8 (with 6 queues: 10.8 either way, with 4: 15.6 either way).
 
     `buckets` = [(begin, end, wait)] (executor.FusedFPDStep.grad_buckets): the flat gradient arena is laid out in the
     order gradients complete during the backward (graph.ParamTable buckets: last stack first), so each bucket is one
@@ -43,7 +53,7 @@ def make_allreduce(dist, group=None):
         return 1e3 * sum(a.elapsed_time(b) for a, b in spans) / len(spans)
 
     def hook(flat_grad, buckets=None):
-        if not buckets or not flat_grad.is_cuda:
+        if not buckets or not flat_grad.is_cuda or os.environ.get('FPD_ALLREDUCE_BUCKETS', '0') != '1':
             work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
             return timed(work.wait) if flat_grad.is_cuda else work.wait     # current stream waits for the collective; no host sync on RCCL
         if 's' not in comm:
