@@ -93,10 +93,13 @@ int fpd_set_backend(int32_t backend) {
     return prev;
 }
 
+static int g_wgrad_tile_only = 0;      // tests: fail instead of falling through to the generic weight-gradient kernels
+
 int fpd_set_option(const char* name, int32_t value) {
     FPD_REQUIRE(name, "set_option: null name");
     if (!strcmp(name, "conv_pp")) return fpd_conv_pp_option(0, value);
     if (!strcmp(name, "conv_pp_blocks")) return fpd_conv_pp_option(1, value);
+    if (!strcmp(name, "wgrad_tile_only")) { g_wgrad_tile_only = value; return 0; }
     return fpd_fail(-2, "set_option: unknown option '%s'", name);
 }
 
@@ -252,6 +255,7 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->partial == nullptr || a->partial_stride >= (int64_t)a->K * a->R * a->S * a->C + a->K,
                 "wgrad: partial_stride %lld smaller than weight + bias", (long long)a->partial_stride);
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_tile_launch(*a, st);
+    FPD_REQUIRE(!(g_wgrad_tile_only && rc == 1), "wgrad: option wgrad_tile_only is set and the halo-tile kernel declines N=%d H=%d W=%d C=%d K=%d R=%d", a->N, a->H, a->W, a->C, a->K, a->R);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
     return rc ? rc : check_launch();

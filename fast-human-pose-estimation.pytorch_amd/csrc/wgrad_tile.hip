@@ -48,7 +48,10 @@ struct WFrag<float> {
     }
 };
 
-template <typename T, int R, int TP>
+// H4 (bf16, 3x3, W a multiple of 4 but not of 16: HRNet's 24- / 12-wide maps): a 16-pixel k-step may straddle image rows,
+// so every 4-pixel group of the transposing read (the granularity at which a lane addresses rows) gets its own halo base,
+// row-validity test and liveness instead of one per k-step.
+template <typename T, int R, int TP, bool H4>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int nrows, const unsigned mW, const int ctiles,
                                                          const int mtiles, const int dbg) {
     using WF = WFrag<T>;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, C = a.C, K = a.K, pad = a.pad;
     const int GR = a.N * H;
+    const unsigned mH = (unsigned)((0x100000000ull / (unsigned long long)H) + 1ull);   // g / H by multiply-high (H4 only)
     // a tile = nrows whole image rows = TPX <= TP pixels (W a power of two: TPX == TP; HRNet's 96- / 48-wide maps: 96 of 128)
     const int hrows = nrows + R - 1, WP = W + R - 1;
     const int HP = hrows * WP, TPX = nrows * W;
@@ -237,8 +241,48 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
 #pragma unroll
             for (int i = 0; i < NS; ++i) WF::mma(af, bf[i], acc[i]);
         };
+        // H4: per-lane 4-pixel groups q = 0 (rows +0..3 of this lane's half), 1 (rows +4..7)
+        auto kstep4 = [&](int pix0) {
+            if constexpr (H4) {
+                const int s16 = lane & 15, gq = (lane >> 4) & 1, half = lane >> 5;
+                const int inrow = (s16 >> 2) * LD + 16 * gq + 4 * (s16 & 3);        // this lane's row / column inside a 4 x 32 group
+                const bf16_t* ap[2];
+                int hb[2], prow[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int px = pix0 + 8 * half + 4 * q;
+                    const int ti = (int)__umulhi((unsigned)px, mW), j0 = px - ti * W;
+                    const int g = g0 + ti;
+                    const int p = g - (int)__umulhi((unsigned)g, mH) * H;
+                    const bool live = g < GR && px < TPX;
+                    ap[q] = (live ? sD + px * LD : sZ) + inrow + ki * 32;
+                    hb[q] = (ti * WP + j0) * LD + inrow + ci * 32;
+                    prow[q] = live ? p : -(1 << 20);
+                }
+                union { struct { s16x4 a, b; } h; bf16x8 f; } ua;
+                ua.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap[0]));
+                ua.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap[1]));
+                bf16x8 bf[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    union { struct { s16x4 a, b; } h; bf16x8 f; } ub;
+                    const bool in0 = (unsigned)(prow[0] + slot_r[i] - pad) < (unsigned)H;
+                    const bool in1 = (unsigned)(prow[1] + slot_r[i] - pad) < (unsigned)H;
+                    const bf16_t* b0 = in0 ? sH + hb[0] + tap_off[i] : sZ + inrow;
+                    const bf16_t* b1 = in1 ? sH + hb[1] + tap_off[i] : sZ + inrow;
+                    ub.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0));
+                    ub.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b1));
+                    bf[i] = ub.f;
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.f, bf[i], acc[i], 0, 0, 0);
+            }
+        };
         if (dbg & 2) continue;
-        if (NS == 1) {
+        if (H4) {
+#pragma unroll 1
+            for (int pix0 = 0; pix0 < TPX; pix0 += KSTEP) kstep4(pix0);
+        } else if (NS == 1) {
 #pragma unroll 4
             for (int pix0 = (KSPLIT ? kgrp * KSTEP : 0); pix0 < TPX; pix0 += (KSPLIT ? 2 : 1) * KSTEP) kstep(pix0);
         } else {
@@ -311,13 +355,19 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     }
 }
 
-struct WtGrid { int nrows, tp, gx, gy, ctiles, mtiles, slabs; };
+struct WtGrid { int nrows, tp, gx, gy, ctiles, mtiles, slabs; bool h4; };
 
 // single source of truth for the launch geometry (also tells the caller how many partial slabs will be written)
 bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
-    const int kstep = a.dtype == FPD_BF16 ? 16 : 2;          // pixels per MFMA k-step: a k-step must stay inside one image row
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 16 || a.W % kstep != 0) return false;
+    // pixels per MFMA k-step: 16 (bf16) / 2 (fp32).  A k-step must stay inside one image row -- except in the bf16 H4 variant
+    // (3x3, W % 4 == 0), which resolves rows per 4-pixel group, and for bf16 1x1 (no halo: the tile is flat, ragged rows are
+    // zero on the dy side)
+    const int kstep = a.dtype == FPD_BF16 ? 16 : 2;
+    const bool row_aligned = a.W % kstep == 0;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < (row_aligned ? 16 : 12)) return false;
+    if (!row_aligned && !(a.dtype == FPD_BF16 && a.W % 4 == 0)) return false;
+    g.h4 = !row_aligned && a.R == 3;
     if (a.C % 16 != 0 || a.K % 16 != 0) return false;
     const int vec = a.dtype == FPD_BF16 ? 8 : 4, cw = a.dtype == FPD_BF16 ? 64 : 32;
     // 1x1: no halo, HBM-bound -> 256-pixel tiles double the bytes in flight per block and halve the barriers
@@ -338,7 +388,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     return true;
 }
 
-template <typename T, int R, int TP>
+template <typename T, int R, int TP, bool H4 = false>
 int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     constexpr int CW = 128 / (int)sizeof(T);
     constexpr int LD = CW + 16 / (int)sizeof(T);
@@ -346,13 +396,13 @@ int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + TP + 16) * LD * sizeof(T);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP, H4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
     static const int dbg = getenv("FPD_WGRAD_DBG") ? atoi(getenv("FPD_WGRAD_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
+    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP, H4>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
                        (unsigned)((0x100000000ull / (unsigned long long)a.W) + 1ull), g.ctiles, g.mtiles, dbg);
     return 0;
 }
@@ -389,6 +439,7 @@ int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
     if (a.partial != nullptr && a.partial_stride < (int64_t)a.K * a.R * a.S * a.C + a.K)
         return fpd_fail(-2, "wgrad: partial_stride %lld smaller than weight + bias", (long long)a.partial_stride);
     if (a.partial == nullptr) g.gx = 1;      // no slabs: one block per (k, c) tile adds straight into dw (deterministic, slow)
+    if (g.h4) return launch_wt<bf16_t, 3, 128, true>(a, g, st);
     if (a.R == 3) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 3, 128>(a, g, st) : launch_wt<float, 3, 128>(a, g, st);
     if (g.tp == 256) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 256>(a, g, st) : launch_wt<float, 1, 256>(a, g, st);
     return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 128>(a, g, st) : launch_wt<float, 1, 128>(a, g, st);

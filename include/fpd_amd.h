@@ -495,8 +495,9 @@ const char* fpd_last_error(void);
 int fpd_set_backend(int32_t backend);         /* FPD_BACKEND_*; returns previous */
 /* run-time knobs (process-wide; the defaults are what the product uses): "conv_pp" = 0 never / 1 launches with >= 256 pixel
  * tiles (default) / 2 whenever in its domain: use of the persistent convolution kernel for big maps (csrc/conv_pp.hip);
- * "conv_pp_blocks" = its persistent blocks per occupancy slot (default 128).  Returns the previous value (>= 0), negative =
- * unknown option. */
+ * "conv_pp_blocks" = its persistent blocks per occupancy slot (default 128); "wgrad_tile_only" = 1: fpd_conv_wgrad() fails
+ * instead of falling through to the generic kernels when the halo-tile kernel declines a shape (tests).  Returns the
+ * previous value (>= 0; 0 for "wgrad_tile_only"), negative = unknown option. */
 int fpd_set_option(const char* name, int32_t value);
 int fpd_abi_sizeof(const char* struct_name);  /* sizeof of a struct above, -1 if unknown */
 int fpd_abi_version(void);

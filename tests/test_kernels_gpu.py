@@ -359,14 +359,19 @@ def test_conv_dgrad_bnrelu_epilogue(case, dtype, backend):
 WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), (1, 9, 7, 16, 16, 3, 1, False),
                (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True),
                (32, 4, 4, 64, 64, 3, 1, True), (32, 8, 8, 64, 64, 3, 1, True), (32, 4, 4, 128, 64, 1, 0, True),   # deepest hourglass levels
-               (2, 16, 48, 32, 64, 3, 1, True), (3, 32, 24, 64, 64, 3, 1, True), (2, 64, 48, 32, 32, 1, 0, False)]   # HRNet map widths
+               (2, 16, 48, 32, 64, 3, 1, True), (3, 32, 24, 64, 64, 3, 1, True), (2, 64, 48, 32, 32, 1, 0, False),   # HRNet map widths
+               (3, 16, 12, 128, 128, 3, 1, True), (2, 32, 24, 64, 32, 1, 0, True), (5, 16, 12, 128, 64, 1, 0, False),
+               (32, 32, 24, 64, 64, 3, 1, True)]
+TILE_ONLY_CASES = WGRAD_CASES[-7:]      # every HRNet width that is a multiple of 4 must be taken by the halo-tile kernel
 
 
-@pytest.mark.parametrize('backend', BACKENDS + ['partials'])
+@pytest.mark.parametrize('backend', BACKENDS + ['partials', 'tile_only'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', WGRAD_CASES)
 def test_conv_wgrad(case, dtype, backend):
     N, H, W, C, K, Rr, pad, use_bn = case
+    if backend == 'tile_only' and (case not in TILE_ONLY_CASES or dtype != 1):
+        pytest.skip('halo-tile-kernel-only run: bf16 HRNet widths')
     gen = torch.Generator().manual_seed(11 + sum(case[:7]))
     bt = Bench(dtype)
     P, Q = H + 2 * pad - Rr + 1, W + 2 * pad - Rr + 1
@@ -385,6 +390,12 @@ def test_conv_wgrad(case, dtype, backend):
     if backend == 'partials':          # default dispatch with the two-stage (slab + reduce) flush instead of atomics
         bt.realise().run([op], 0, partials=True)
         assert bt.n_partial_ops == 1           # every weight-gradient kernel writes slabs (no floating-point atomics)
+    elif backend == 'tile_only':       # the library refuses to fall through to the generic kernels: wgrad_tile must take it
+        R.set_option('wgrad_tile_only', 1)
+        try:
+            bt.realise().run([op], 0, partials=True)
+        finally:
+            R.set_option('wgrad_tile_only', 0)
     else:
         bt.realise().run([op], backend)
     m = N * P * Q
