@@ -35,6 +35,8 @@ int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipS
 int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_wgrad_tile_partials(const fpd_wgrad_t& a);
+int fpd_wgrad_smallc_launch(const fpd_wgrad_t& a, hipStream_t st);
+int fpd_wgrad_smallc_partials(const fpd_wgrad_t& a);
 int fpd_wgrad_mfma_partials(const fpd_wgrad_t& a);
 int fpd_wgrad_naive_partials(const fpd_wgrad_t& a);
 int fpd_stem_wgrad_mfma_partials(const fpd_stem_t& a);
@@ -257,6 +259,7 @@ int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream) {
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_wgrad_tile_launch(*a, st);
     FPD_REQUIRE(!(g_wgrad_tile_only && rc == 1), "wgrad: option wgrad_tile_only is set and the halo-tile kernel declines N=%d H=%d W=%d C=%d K=%d R=%d", a->N, a->H, a->W, a->C, a->K, a->R);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_mfma_launch(*a, st);
+    if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_wgrad_smallc_launch(*a, st);
     if (rc == 1) rc = fpd_wgrad_naive_launch(*a, st);
     return rc ? rc : check_launch();
 }
@@ -267,6 +270,7 @@ int fpd_wgrad_num_partials(const fpd_wgrad_t* a) {
     int n = 0;
     if (g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_wgrad_tile_partials(*a);
     if (n == 0 && g_fpd_backend != FPD_BACKEND_NAIVE) n = fpd_wgrad_mfma_partials(*a);
+    if (n == 0 && g_fpd_backend != FPD_BACKEND_NAIVE) n = fpd_wgrad_smallc_partials(*a);
     if (n == 0) n = fpd_wgrad_naive_partials(*a);
     return n;
 }

@@ -159,7 +159,129 @@ int dispatch_smallc(const fpd_conv_t& a, hipStream_t st) {
     return 1;
 }
 
+// ---- weight gradient of a convolution with a tiny reduction footprint per pixel (R*S*C <= 32): HRNet's first stem
+// convolution (3x3 / stride 2, C = 3, K = 64: pose_hrnet.py:279), whose weight gradient is the LAST launch of the backward
+// and therefore fully exposed in front of Adam (1.19 ms through the one-thread-per-weight kernel).
+//   dw[k][r][s][c] = sum_m dy[m][k] * x[m*stride - pad + (r, s)][c]
+// A 256-thread block walks 128-pixel tiles persistently: the dy tile goes to LDS as fp32 [128][64], the im2col rows of the
+// tile as fp32 [128][32] (zero where the tap falls outside the image); thread (k = tid % 64, tg = tid / 64) owns the eight
+// im2col columns 8 tg .. 8 tg + 7 of output channel k: per pixel one conflict-free read of dy and two 16-byte reads of
+// im2col values whose address is uniform over the wave (broadcast).  One slab per block at the end, no atomics.
+constexpr int WS_TP = 128, WS_COLS = 32, WS_KB = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_smallc_kernel(const fpd_wgrad_t a, const int ntiles) {
+    constexpr int VEC = DT<T>::VEC;
+    __shared__ __attribute__((aligned(16))) float s_dy[WS_TP * WS_KB];
+    __shared__ __attribute__((aligned(16))) float s_col[WS_TP * WS_COLS];
+    __shared__ int s_pix[WS_TP * 3];                    // image, first input row, first input column of every tile pixel
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, S = a.S, P = a.P, Q = a.Q;
+    const int M = a.N * P * Q, RSC = R * S * C, PQ = P * Q;
+    const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+    const int k = tid & (WS_KB - 1), tg = tid >> 6;
+    // im2col column t -> (r, s, c), fixed per gather slot of this thread: slot i handles element tid + 256 i of [128][32]
+    int g_r[16], g_s[16], g_c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int t = (tid + 256 * i) & (WS_COLS - 1);
+        const int rs = t / C;
+        g_c[i] = t - rs * C; g_r[i] = rs / S; g_s[i] = rs - (rs / S) * S;
+        if (t >= RSC) g_r[i] = -(1 << 20);              // padding columns stay zero
+    }
+    float acc[8], bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int kvec = K / VEC;                           // 16-byte vectors per dy pixel (K % VEC == 0, K <= 64)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * WS_TP;
+        __syncthreads();                                // previous tile consumed
+        if (tid < WS_TP) {
+            const int m = m0 + tid;
+            const int n = m / PQ, rem = m - n * PQ;
+            const int pp = rem / Q, q = rem - pp * Q;
+            s_pix[tid * 3] = m < M ? n : -1;
+            s_pix[tid * 3 + 1] = pp * a.stride - a.pad;
+            s_pix[tid * 3 + 2] = q * a.stride - a.pad;
+        }
+        for (int v = tid; v < WS_TP * (WS_KB / VEC); v += 256) {       // dy tile, zero beyond K / M
+            const int p = v / (WS_KB / VEC), cv = v - p * (WS_KB / VEC);
+            float f[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+            if (m0 + p < M && cv < kvec) {
+                if (VEC == 8) DT<T>::unpack(*reinterpret_cast<const uint4*>(dy + (size_t)(m0 + p) * K + cv * VEC), f);
+                else {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(dy + (size_t)(m0 + p) * K + cv * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] = t4[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4)
+                *reinterpret_cast<f32x4*>(s_dy + p * WS_KB + cv * VEC + e) = f32x4{f[e], f[e + 1], f[e + 2], f[e + 3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                  // im2col gather
+            const int e = tid + 256 * i, p = e >> 5;
+            const int n = s_pix[p * 3], ih = s_pix[p * 3 + 1] + g_r[i], iw = s_pix[p * 3 + 2] + g_s[i];
+            float v = 0.f;
+            if (n >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                v = DT<T>::ld(x + ((size_t)(n * H + ih) * W + iw) * C + g_c[i]);
+            s_col[e] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < WS_TP; ++p) {
+            const float g = s_dy[p * WS_KB + k];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_col + p * WS_COLS + tg * 8);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(s_col + p * WS_COLS + tg * 8 + 4);
+            bsum += g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] = fmaf(g, c0[j], acc[j]); acc[4 + j] = fmaf(g, c1[j], acc[4 + j]); }
+        }
+    }
+    // flush: slab blockIdx.x (layout of dw, bias sums behind it) or, single block without slabs, straight into dw
+    if (k < K) {
+        float* dst = a.partial != nullptr ? a.partial + (size_t)blockIdx.x * a.partial_stride : a.dw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = tg * 8 + j;
+            if (t < RSC) {
+                if (a.partial != nullptr) dst[k * RSC + t] = acc[j];
+                else dst[k * RSC + t] += acc[j];
+            }
+        }
+        if (a.dbias != nullptr && tg == 0) {
+            if (a.partial != nullptr) dst[(size_t)K * RSC + k] = bsum;
+            else a.dbias[k] += bsum;
+        }
+    }
+}
+
+static bool wgrad_smallc_domain(const fpd_wgrad_t& a) {
+    if (a.bn.mode != FPD_BN_NONE || a.R * a.S * a.C > WS_COLS || a.K > WS_KB) return false;
+    return a.K % (a.dtype == FPD_BF16 ? 8 : 4) == 0;
+}
+static int wgrad_smallc_blocks(const fpd_wgrad_t& a) {
+    return std::max(1, std::min(512, cdiv(a.N * a.P * a.Q, WS_TP)));
+}
+
 }  // namespace
+
+// slabs a launch writes (0 = outside the domain); 1 = fpd_wgrad_smallc_launch declined
+int fpd_wgrad_smallc_partials(const fpd_wgrad_t& a) { return wgrad_smallc_domain(a) ? wgrad_smallc_blocks(a) : 0; }
+
+int fpd_wgrad_smallc_launch(const fpd_wgrad_t& a, hipStream_t st) {
+    if (!wgrad_smallc_domain(a)) return 1;
+    const int ntiles = cdiv(a.N * a.P * a.Q, WS_TP);
+    const int blocks = a.partial != nullptr ? wgrad_smallc_blocks(a) : 1;     // no slabs: one block owns every sum (deterministic, slow)
+    if (a.dtype == FPD_BF16) hipLaunchKernelGGL((wgrad_smallc_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a, ntiles);
+    else hipLaunchKernelGGL((wgrad_smallc_kernel<float>), dim3(blocks), dim3(256), 0, st, a, ntiles);
+    return 0;
+}
 
 // 1 = outside this kernel's domain (the caller falls through to the direct cross-check kernel)
 int fpd_conv_smallc_launch(const fpd_conv_t& a, hipStream_t st) {
