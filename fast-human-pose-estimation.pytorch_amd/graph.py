@@ -24,6 +24,7 @@ STATS_REPLICAS = int(os.environ.get('FPD_STATS_REPLICAS', '4'))   # include/fpd_
 # LANE_LEVELS largest resolutions get a lane, and weight gradients are issued in batches of WGRAD_BATCH on one lane.
 WGRAD_LANES = 1
 LANE_LEVELS = 0
+WREDUCE_PER_BATCH = os.environ.get('FPD_WREDUCE_PER_BATCH', '0') == '1'   # slab reduction per weight-gradient batch instead of once per gradient bucket (measured equal: 10.67 vs 10.67 ms, 22 more launches)
 WGRAD_BATCH = 8     # re-swept in round 2 on one box: 1/2/4/8/12/16/24/32 -> 11.92/11.83/11.69/11.67/11.81/11.83/11.90/11.99 ms (the lane tail before Adam)
 
 
@@ -713,22 +714,24 @@ class HourglassGraph:
         """All forward ops owning parameters of bucket b have been differentiated: issue the remaining weight gradients,
         reduce the bucket's slabs and mark the point where its slice of the gradient arena is final (the data-parallel
         all-reduce of that slice can start there, overlapping the rest of the backward)."""
-        self._flush_wgrads()
-        lane = 1 + self.depth
-        if self._wg_bucket:
-            bufs = [x for w in self._wg_bucket for x in (w.dw, w.dbias) if x is not None]
-            self.bwd.append(Op('wreduce', bucket=b, wgrads=list(self._wg_bucket), bufs=bufs, lane=lane))
-        self._wg_bucket = []
-        self.bwd.append(Op('grad_ready', bucket=b, region=self.p.grad_bucket(b), lane=lane))
+        self._flush_wgrads(b, reduce=True)
+        self.bwd.append(Op('grad_ready', bucket=b, region=self.p.grad_bucket(b), lane=1 + self.depth))
 
-    def _flush_wgrads(self):
+    def _flush_wgrads(self, b=None, reduce=None):
         """Weight gradients are leaves: they are collected and issued in batches on their own lane, newest first, so
-        that the batch's first kernel carries the one cross-lane wait that covers the whole batch."""
+        that the batch's first kernel carries the one cross-lane wait that covers the whole batch.  The slabs of a batch
+        are summed right behind it (WREDUCE_PER_BATCH; always at the end of a bucket): the reduction that remains in
+        front of Adam after the last data gradient then covers the last batch only, not the whole last bucket."""
         for w in reversed(self._wg_pending):
             self.bwd.append(w)
             if w.kind == 'wgrad':
                 self._wg_bucket.append(w)
         self._wg_pending = []
+        if (WREDUCE_PER_BATCH if reduce is None else reduce) and self._wg_bucket:
+            bufs = [x for w in self._wg_bucket for x in (w.dw, w.dbias) if x is not None]
+            self.bwd.append(Op('wreduce', bucket=self._cur_bucket if b is None else b, wgrads=list(self._wg_bucket), bufs=bufs,
+                               lane=1 + self.depth))
+            self._wg_bucket = []
 
     def _emit_dgrad(self, op):
         c = self._pair_op
@@ -776,7 +779,9 @@ class HourglassGraph:
                 # The data gradient of a 1x1 convolution reads dy and the forward operand's source anyway: where the library
                 # offers it (fpd_conv_fused_wgrad_partials, asked at lowering time) the launch also forms that convolution's
                 # weight gradient and the separate 'wgrad' op becomes a no-op (executor.Lowering.conv).
-                if R == 1 and stride == 1 and dy is op.y.grad:
+                # (only while that 'wgrad' is still pending: once its batch -- and the batch's slab reduction -- has been
+                # issued, the slabs of a later launch would never be summed)
+                if R == 1 and stride == 1 and dy is op.y.grad and any(w is wg for w in self._wg_pending):
                     d.fused_wgrad = wg
                 self._emit_dgrad(d)
             self._bn_backward_contribution(x, op.bn, make)
