@@ -60,7 +60,7 @@ def _abuf(a):
 
 
 # FPD_WHATIF=token[,token...]: TIMING-ONLY experiments (results are wrong when set): the named class of ops is lowered to
-# no-ops, which shows what that class costs inside the pipelined step (tools/probes/r03_whatif.sh).  Student graph:
+# no-ops, which shows what that class costs inside the pipelined step (experiments/r03/whatif.sh).  Student graph:
 # nowgrad / nowgrad_small / nowgrad_big (weight gradients, by map height <= 16 / >= 64), noapply (BN-backward applies),
 # nobigconv (convolutions on >= 64x64 maps), nobig / nomid / nosmall (every op on >= 64 / 32 / <= 16 high maps, weight
 # gradients excepted), noew.  Teacher graph: t_all, t_big, t_mid, t_small.
