@@ -554,10 +554,18 @@ def main():
         t_cpu = time.time()
         out['cpu_baseline'] = cpu_baseline_hrnet() if hr else cpu_baseline()
         print('[bench] cpu baseline took %.1f s' % (time.time() - t_cpu), file=sys.stderr, flush=True)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # the JSON line must be the LAST line of stdout: RCCL prints a version banner through C stdio, which (block-buffered when
+    # stdout is a pipe or file) would otherwise be flushed at process exit, i.e. after this line -- every rank empties its C
+    # buffer before the final barrier, rank 0 prints behind it
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
