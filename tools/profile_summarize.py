@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Aggregates the rocprofv3 output of tools/profile_r02.sh into the small tables kept under profiles/:
-  r02_kernel_stats.csv      rocprofv3's own --stats table
-  r02_per_shape.csv         per (kernel, grid): calls per step, average us, ms per step (the --stats averages mix shapes)
-  r02_hbm_traffic.csv       per (kernel, grid): FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes), HBM bytes per launch
+"""Aggregates the rocprofv3 output of tools/profile.sh into the small tables kept under profiles/ (rNN = the prefix argument):
+  rNN_kernel_stats.csv      rocprofv3's own --stats table
+  rNN_per_shape.csv         per (kernel, grid): calls per step, average us, ms per step (the --stats averages mix shapes)
+  rNN_hbm_traffic.csv       per (kernel, grid): FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes), HBM bytes per launch
                             = (2 x FETCH + WRITE) x 1024 (gfx950: FETCH_SIZE counts wide coalesced reads at 1/2, MI355X_MICROARCH.md),
                             average duration from the un-counted trace, GB/s and the fraction of the 8 TB/s HBM3E peak
-  r02_pmc_bneck64.json      the same for the dominant kernel from its micro-benchmark (what bench.py's roofline.traffic quotes)"""
+  rNN_pmc_bneck64.json      the same for the dominant kernel from its micro-benchmark (what bench.py's roofline.traffic quotes)"""
 import collections
 import csv
 import glob
@@ -16,7 +16,7 @@ import sys
 
 out = sys.argv[1]
 PFX = sys.argv[2] if len(sys.argv) > 2 else 'r02'
-STEPS = 26        # 1 eager + 5 warm-up + 20 timed steps in the --stats run
+STEPS = None      # set from the trace: one adam_kernel launch per student step (eager + warm-up + timed + the host-enqueue probe step)
 
 
 def short(n):
@@ -34,7 +34,14 @@ def trace(sub):
 for f in glob.glob('%s/stats/**/*kernel_stats.csv' % out, recursive=True):
     shutil.copy(f, os.path.join(out, PFX + '_kernel_stats.csv'))
 dur = collections.defaultdict(list)
-for r in trace('stats'):
+rows_stats = sorted(trace('stats'), key=lambda r: int(r['Start_Timestamp']))
+adams = [i for i, r in enumerate(rows_stats) if 'adam_kernel' in r['Kernel_Name']]
+STEPS = len(adams)
+# bench.py re-times single recorded ops live after its last step (roofline.avg_us, conv_classes): not part of a step
+tail = sum(1 for r in rows_stats[adams[-1] + 1:] if 'adam_tick' not in r['Kernel_Name'])
+rows_stats = rows_stats[:adams[-1] + 2]
+print('%d steps in the trace; %d kernel records behind the last step (live re-timing of single ops) left out' % (STEPS, tail))
+for r in rows_stats:
     grid = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
     wg = int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
     dur[(short(r['Kernel_Name']), str(grid), str(wg))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
