@@ -9,13 +9,15 @@ N>1: one rank per GPU.  Started without a torch.distributed environment (no WORL
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`;
 started by torch.distributed.run (the driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant single-shape kernel of the step -- the fused frozen
-Bottleneck of the teacher at 64x64 (17 launches/step, the largest single (kernel, shape) entry of the rocprof trace) --
-with its algorithmic conv FLOPs against the dense bf16 MFMA peak, timed live with HIP events on the launch stream;
-`roofline.step` prices one whole step (79.478 GFLOP per image) the same way.
+Prints ONE JSON line on rank 0 (the last line of stdout).  `roofline` prices the dominant single-shape kernel of the step
+-- the fused frozen Bottleneck of the teacher at 64x64 (17 launches/step: 9 alone, 8 paired with a 32x32 one; the largest
+single (kernel, shape) entry of the rocprof trace) -- with its algorithmic conv FLOPs against the dense bf16 MFMA peak,
+timed live with HIP events on the launch stream; `roofline.step` prices one whole step (79.478 GFLOP per image, SURVEY.md
+section 8(d)) the same way; `roofline.conv_classes` lists the costliest convolution classes of the step, each timed from
+the step's own plan (`--config hrnet`: its top entry IS the roofline kernel).
 `cpu_baseline` times the CPU oracle (restatement of the reference loop) on a bounded sample of the same workload on the
-host cores: thread count swept on the small configuration, both the reference-faithful variant (teacher graph retained,
-function.py:120) and the teacher-under-no_grad variant, at cfg-1 (hg2x64, B=2) and the benchmark pair (B=4).
+host cores: thread count swept per configuration, both the reference-faithful variant (teacher graph retained,
+function.py:120) and the teacher-under-no_grad variant, 3 timed steps each at cfg-1 (hg2x64, B=2) and the benchmark pair (B=8).
 """
 import argparse
 import json
@@ -61,41 +63,46 @@ def _cpu_time(pair, batch, steps, no_grad, seed=0):
 
 
 def cpu_baseline():
-    """the oracle on the GPU box's host cores.  Thread count swept on cfg-1 (one timed step each), then
-    the best count times cfg-1 (hg2x64, B=2) and the benchmark pair (hg4x128 <- hg8x256, B=8) with 3 timed steps after one
-    warm-up each, both with the teacher under no_grad and reference-faithful (teacher graph retained, function.py:120; if the
-    budget of ~90 s is exhausted the faithful B=8 variant falls back to fewer steps and says so).  `value` = images/s of
-    the benchmark pair with the teacher under no_grad (the faster variant: the stronger baseline)."""
+    """the oracle on the GPU box's host cores.  The thread count is swept SEPARATELY for cfg-1 (hg2x64,
+    B=2) and for the benchmark pair (hg4x128 <- hg8x256, B=8) -- one timed step per count after a warm-up, stopping when a
+    count is clearly slower than the best so far: the small pair wants few threads, the big one more -- then each pair is
+    timed with its best count for 3 steps after one warm-up, both with the teacher under no_grad and reference-faithful
+    (teacher graph retained, function.py:120; fewer steps, and said so, if the ~100 s budget is exhausted).  `value` =
+    images/s of the benchmark pair with the teacher under no_grad (the faster variant: the stronger baseline)."""
     ncpu = os.cpu_count() or 1
     cfg1, pair = ((64, 2), (64, 2)), ((128, 4), (256, 8))
     t_begin = time.time()
-    sweep = {}
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):          # beyond 64 threads these small convolutions only lose
-        torch.set_num_threads(nt)
-        sweep[nt] = round(2 / _cpu_time(cfg1, 2, 1, True), 3)
-        if time.time() - t_begin > 20:
-            break
-    best = max(sweep, key=sweep.get)
-    torch.set_num_threads(best)
+
+    def sweep(p, batch, counts, budget_s):
+        res, t0 = {}, time.time()
+        for nt in sorted({min(ncpu, n) for n in counts}):
+            torch.set_num_threads(nt)
+            res[nt] = round(batch / _cpu_time(p, batch, 1, True), 3)
+            if res[nt] < 0.7 * max(res.values()) or time.time() - t0 > budget_s:
+                break
+        return res, max(res, key=res.get)
     variants = []
 
-    def run(name, p, batch, steps, no_grad):
+    def run(name, p, batch, steps, no_grad, nt):
+        torch.set_num_threads(nt)
         dt = _cpu_time(p, batch, steps, no_grad)
-        variants.append({'config': name, 'batch': batch, 'teacher': 'no_grad' if no_grad else 'graph retained (reference-faithful)',
+        variants.append({'config': name, 'batch': batch, 'threads': nt, 'teacher': 'no_grad' if no_grad else 'graph retained (reference-faithful)',
                          'timed_steps': steps, 's_per_step': round(dt, 3), 'images_per_s': round(batch / dt, 3)})
         return batch / dt
-    run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, True)
-    run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, False)
+    sweep1, best1 = sweep(cfg1, 2, (8, 16, 32, 64), 15)          # beyond 64 threads these small convolutions only lose
+    run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, True, best1)
+    run('cfg-1 hg2x64 <- hg2x64', cfg1, 2, 3, False, best1)
     big_b = 8
-    v = run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 3, True)
-    left = 90 - (time.time() - t_begin)
-    per = variants[-1]['s_per_step'] * 2.0                               # the retained teacher graph costs about 2x
+    sweep2, best2 = sweep(pair, big_b, (8, 16, 32, 64, 128), 35)
+    v = run('cfg-2 hg4x128 <- hg8x256', pair, big_b, 3, True, best2)
+    left = 100 - (time.time() - t_begin)
+    per = variants[-1]['s_per_step'] * 1.5                               # the retained teacher graph costs about 1.4x
     steps_f = 3 if per * 4 < left else max(1, int(left / per) - 1)
-    run('cfg-2 hg4x128 <- hg8x256', pair, big_b, steps_f, False)
-    return {'value': round(v, 3), 'unit': 'images/s', 'cores': best, 'kind': 'port',
+    run('cfg-2 hg4x128 <- hg8x256', pair, big_b, steps_f, False, best2)
+    return {'value': round(v, 3), 'unit': 'images/s', 'cores': best2, 'kind': 'port',
             'sample': 'same FPD pair (hg4x128 <- hg8x256, 256x256) at batch %d, 3 timed steps after 1 warm-up, torch CPU fp32 '
-                      'oracle, teacher under no_grad, %d threads (best of the sweep on %d host CPUs)' % (big_b, best, ncpu),
-            'thread_sweep_cfg1_images_per_s': sweep, 'variants': variants}
+                      'oracle, teacher under no_grad, %d threads (best of a sweep on this pair; %d host CPUs)' % (big_b, best2, ncpu),
+            'thread_sweep_cfg1_images_per_s': sweep1, 'thread_sweep_cfg2_images_per_s': sweep2, 'variants': variants}
 
 
 def hr_extra(widths):
@@ -488,7 +495,7 @@ def main():
                     'grid_cap': dom['grid_cap'], 'traffic_source': traffic_note,
                     'note': 'dominant (kernel, shape) of the step, timed AS LAUNCHED IN THE STEP (persistent grid capped at '
                             'FPD_BNECK_BLOCKS of 256 CUs so that the concurrent student chain finds free compute units; uncapped the '
-                            'same kernel runs ~100 us = 0.22 of peak, DESIGN.md section 5); %d back-to-back launches timed with HIP '
+                            'same kernel runs 86.5 us = 0.26 of peak, DESIGN.md section 5); %d back-to-back launches timed with HIP '
                             'events on the launch stream after the timed region; traffic = HBM bytes/launch from rocprofv3 --pmc '
                             'passes at the same grid cap (profiles/), null if absent' % dom['launches'],
                     'step': step_roof}
