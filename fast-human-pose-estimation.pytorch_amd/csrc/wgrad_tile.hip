@@ -51,14 +51,16 @@ struct WFrag<float> {
 // H4 (bf16, 3x3, W a multiple of 4 but not of 16: HRNet's 24- / 12-wide maps): a 16-pixel k-step may straddle image rows,
 // so every 4-pixel group of the transposing read (the granularity at which a lane addresses rows) gets its own halo base,
 // row-validity test and liveness instead of one per k-step.
-template <typename T, int R, int TP, bool H4>
+// SMALL (bf16, 3x3, C <= 32 and K <= 32: HRNet-W32's first branch): only the (0, 0) 32x32 sub-tile of the block's K x C plane
+// is live, so the nine taps -- not 9 x 4 sub-tiles, three quarters of them zero -- are spread over the waves.
+template <typename T, int R, int TP, bool H4, bool SMALL = false>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int nrows, const unsigned mW, const int ctiles,
                                                          const int mtiles, const int dbg) {
     using WF = WFrag<T>;
     constexpr int VEC = DT<T>::VEC;
     constexpr int CW = 128 / (int)sizeof(T);          // channels per tile row: 64 (bf16) / 32 (fp32) = 128 bytes
     constexpr int LD = CW + 16 / (int)sizeof(T);
-    constexpr int KC1 = CW / 32, KC = KC1 * KC1;      // (ki,ci) sub-tiles of 32x32: 4 / 1
+    constexpr int KC1 = SMALL ? 1 : CW / 32, KC = KC1 * KC1;      // (ki,ci) sub-tiles of 32x32: 4 (bf16) / 1 (fp32, SMALL)
     constexpr int KSTEP = WF::KSTEP;
     constexpr int BLK = 512, NW = BLK / 64;           // 8 waves: two per SIMD, sharing one staged tile
     constexpr int NVH = 2048 / BLK, NVD = TP * 8 / BLK;    // halo / dy 16-byte vectors per thread (TP pixels per tile)
@@ -388,7 +390,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     return true;
 }
 
-template <typename T, int R, int TP, bool H4 = false>
+template <typename T, int R, int TP, bool H4 = false, bool SMALL = false>
 int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     constexpr int CW = 128 / (int)sizeof(T);
     constexpr int LD = CW + 16 / (int)sizeof(T);
@@ -396,13 +398,13 @@ int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + TP + 16) * LD * sizeof(T);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP, H4>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP, H4, SMALL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         configured = lds;
     }
     static const int dbg = getenv("FPD_WGRAD_DBG") ? atoi(getenv("FPD_WGRAD_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP, H4>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
+    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP, H4, SMALL>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
                        (unsigned)((0x100000000ull / (unsigned long long)a.W) + 1ull), g.ctiles, g.mtiles, dbg);
     return 0;
 }
@@ -440,6 +442,7 @@ int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
         return fpd_fail(-2, "wgrad: partial_stride %lld smaller than weight + bias", (long long)a.partial_stride);
     if (a.partial == nullptr) g.gx = 1;      // no slabs: one block per (k, c) tile adds straight into dw (deterministic, slow)
     if (g.h4) return launch_wt<bf16_t, 3, 128, true>(a, g, st);
+    if (a.R == 3 && a.dtype == FPD_BF16 && a.C <= 32 && a.K <= 32) return launch_wt<bf16_t, 3, 128, false, true>(a, g, st);
     if (a.R == 3) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 3, 128>(a, g, st) : launch_wt<float, 3, 128>(a, g, st);
     if (g.tp == 256) return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 256>(a, g, st) : launch_wt<float, 1, 256>(a, g, st);
     return a.dtype == FPD_BF16 ? launch_wt<bf16_t, 1, 128>(a, g, st) : launch_wt<float, 1, 128>(a, g, st);

@@ -360,6 +360,7 @@ WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), 
                (4, 32, 32, 64, 64, 3, 1, True), (2, 8, 8, 64, 128, 1, 0, False), (2, 16, 16, 128, 16, 1, 0, True),
                (32, 4, 4, 64, 64, 3, 1, True), (32, 8, 8, 64, 64, 3, 1, True), (32, 4, 4, 128, 64, 1, 0, True),   # deepest hourglass levels
                (4, 32, 24, 3, 64, 3, 1, False), (2, 16, 12, 3, 16, 3, 1, False), (3, 20, 20, 4, 8, 1, 0, False),   # tiny C: wgrad_smallc
+               (2, 64, 48, 32, 32, 3, 1, True), (2, 16, 16, 16, 32, 3, 1, True), (3, 32, 32, 32, 16, 3, 1, False),   # C, K <= 32: wgrad_tile SMALL
                (2, 16, 48, 32, 64, 3, 1, True), (3, 32, 24, 64, 64, 3, 1, True), (2, 64, 48, 32, 32, 1, 0, False),   # HRNet map widths
                (3, 16, 12, 128, 128, 3, 1, True), (2, 32, 24, 64, 32, 1, 0, True), (5, 16, 12, 128, 64, 1, 0, False),
                (32, 32, 24, 64, 64, 3, 1, True)]
