@@ -706,15 +706,19 @@ class FusedFPDStep:
         """Student prep/forward, fused loss (against the staged teacher map), backward, [all-reduce], Adam."""
         s = self.student
         slot = self._k_s % 2
+        late = os.environ.get('FPD_TEACHER_WAIT', 'loss') == 'loss'
         if self.teacher is not None:
             assert self._k_t > self._k_s, 'teacher_async() must be submitted before student_step()'
-            torch.cuda.current_stream().wait_event(self.ev_t[slot])
+            if not late:
+                torch.cuda.current_stream().wait_event(self.ev_t[slot])
         if self._dist_work is not None:        # previous step's gradient exchange overlapped this step's teacher forward
             self._dist_work()
             self._dist_work = None
             s.run('adam')
         s.run('prep')
         s.run('fwd')
+        if self.teacher is not None and late:  # only the fused loss reads the teacher's map: the student's own forward
+            torch.cuda.current_stream().wait_event(self.ev_t[slot])      # need not wait for a teacher that is still running
         s.run('mid' if slot == 0 else 'mid1')
         if getattr(self, 'metric', None) is not None:
             self.metric.enqueue()
