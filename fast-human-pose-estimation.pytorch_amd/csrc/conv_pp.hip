@@ -91,7 +91,8 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     float* s_shift = s_scale + C;                         // [C]
     float* s_epi = s_shift + C;                           // [4][KP] (BNRELU_BWD)
     float* s_bias = s_epi + 4 * KP;                       // [KP]
-    unsigned char* sW = reinterpret_cast<unsigned char*>(s_bias + KP);
+    float* s_fold = s_bias + KP;                          // BWD: [3][C] coefficients of a folded BN-backward apply (fold_x)
+    unsigned char* sW = reinterpret_cast<unsigned char*>(s_fold + (BWD ? 3 * C : 0));
     unsigned char* sG = sW + RS * KP * C * 2;             // operand image; the waves' epilogue staging tiles alias it
     unsigned char* sS = WG ? sG + geo.region : sG;        // ... unless the weight gradient needs the image after the epilogue
     unsigned char* sAT = sS + 8 * 32 * LDST;              // WG: a(u) tile
@@ -109,6 +110,11 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const bf16_t* res = reinterpret_cast<const bf16_t*>(a.residual);
     const bf16_t* ex = reinterpret_cast<const bf16_t*>(a.epi_x);
     const bool want_stats = BWD || (a.out_stats != nullptr);
+    // FOLDED BN-BACKWARD APPLY (fpd_conv_t.fold_x): the operand proper is dy = A_c g + B_c u + D_c, g = x (the masked
+    // gradient), u = fold_x; evaluated on the way into the operand image, rounded once like the stand-alone apply's output
+    const bool fold = BWD && a.fold_x != nullptr;
+    const bf16_t* __restrict__ fx = reinterpret_cast<const bf16_t*>(a.fold_x);
+    bf16_t* fo = (fold && n0 == 0) ? reinterpret_cast<bf16_t*>(a.fold_out) : nullptr;     // written once: by the first K slab
 
     // ---- this block's tiles: a contiguous range ----
     const int t_beg = (int)((long long)bi * geo.ntiles / geo.nblk);
@@ -119,6 +125,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const int WV = W * CPR, nvtot = hrows * WV;
     const int nvh = (nvtot + 511) >> 9;                   // uniform trip count
     uint4 rh[NVH];
+    uint4 ru[BWD ? NVH : 1];                              // fold: the same vectors of u
     unsigned hmask = 0;
     auto halo_load = [&](int tile) {
         const int g0 = tile * nrows - pad;
@@ -134,6 +141,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                 const int g = g0 + hr;
                 const int gc = min(max(g, 0), GR - 1);
                 rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(gc * W + j) * C + cve));
+                if (BWD && fold) ru[i] = *reinterpret_cast<const uint4*>(fx + ((size_t)(gc * W + j) * C + cve));
                 hmask |= (g == gc ? 1u : 0u) << i;
             }
         }
@@ -143,9 +151,10 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[e] = 0.f;
     const bool wg_bias = wg && a.wg_bias && n0 == 0;
-    auto halo_store = [&]() {
+    auto halo_store = [&](const int tile) {
         const int tl = pp_fresh(tid);
         const int cvb = (tl & (CPR - 1)) * 16;
+        const int g0s = tile * nrows - pad;
         // zero border columns and zero pixels first (the epilogue staging of the previous tile overwrote them)
         {
             const uint4 z = make_uint4(0, 0, 0, 0);
@@ -155,6 +164,13 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                 const int px = pz < nb ? ((pz >> 1) * WP + ((pz & 1) ? WP - 1 : 0)) : zero_px + (pz - nb);
                 *reinterpret_cast<uint4*>(sG + px * LDA + cv) = z;
             }
+        }
+        f32x4 fa0, fa1, fb0, fb1, fd0, fd1;
+        if (BWD && fold) {
+            const float* t = s_fold + (cvb >> 1);
+            fa0 = *reinterpret_cast<const f32x4*>(t); fa1 = *reinterpret_cast<const f32x4*>(t + 4);
+            fb0 = *reinterpret_cast<const f32x4*>(t + C); fb1 = *reinterpret_cast<const f32x4*>(t + C + 4);
+            fd0 = *reinterpret_cast<const f32x4*>(t + 2 * C); fd1 = *reinterpret_cast<const f32x4*>(t + 2 * C + 4);
         }
         f32x4 sc0, sc1, sh0, sh1;
         const bool has_bn = a.bn.mode != FPD_BN_NONE;
@@ -172,6 +188,23 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                 const int hr = pp_qdiv(vc, geo.mWV);
                 const int j = (vc - hr * WV) >> LOG_CPR;
                 uint4 val = rh[i];
+                if (BWD && fold) {
+                    float g[8], u[8];
+                    DT<bf16_t>::unpack(val, g);
+                    DT<bf16_t>::unpack(ru[i], u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g[e] = fmaf(fa0[e], g[e], fmaf(fb0[e], u[e], fd0[e]));
+                        g[4 + e] = fmaf(fa1[e], g[4 + e], fmaf(fb1[e], u[4 + e], fd1[e]));
+                    }
+                    val = DT<bf16_t>::pack(g);
+                    const bool in = (hmask >> i) & 1u;    // rows outside the tensor stay exactly zero (D_c is not)
+                    val.x = in ? val.x : 0u; val.y = in ? val.y : 0u; val.z = in ? val.z : 0u; val.w = in ? val.w : 0u;
+                    // the evaluated operand is written out once for its other consumers (a separate weight-gradient launch):
+                    // rows of this tile proper only -- halo rows belong to the neighbouring tiles
+                    if (fo != nullptr && in && v < nvtot && hr >= pad && hr < pad + nrows)
+                        *reinterpret_cast<uint4*>(fo + ((size_t)((g0s + hr) * W + j) * C + (cvb >> 1))) = val;
+                }
                 if (WG && wg_bias) {
                     float f[8];
                     DT<bf16_t>::unpack(val, f);
@@ -208,7 +241,14 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const bool r_bn = a.bn.mode != FPD_BN_NONE && tid < C;
     const bool r_epi = a.epi == FPD_EPI_BNRELU_BWD && te >= 0 && te < KP;
     const bool r_bias = tb >= 0 && tb < KP;
+    const bool r_fold = fold && tid < C;
+    double fs1[FPD_STATS_REPLICAS], fs2[FPD_STATS_REPLICAS];
     if (r_bn) bn_request(a.bn, tid, C, braw);
+    else if (r_fold) {
+        bn_request(a.fold_bn, tid, C, braw);
+#pragma unroll
+        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { fs1[q] = a.fold_stats[q * 2 * C + tid]; fs2[q] = a.fold_stats[q * 2 * C + C + tid]; }
+    }
     else if (r_epi && n0 + te < K) bn_request(a.epi_bn, n0 + te, K, braw);
     else if (r_bias && a.bias != nullptr && n0 + tb < K) bias_raw = a.bias[n0 + tb];
     __builtin_amdgcn_sched_barrier(0);
@@ -230,6 +270,23 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             bn_resolve(braw, (double)M, sc, sh, mu, is);
             s_scale[tid] = sc;
             s_shift[tid] = sh;
+        } else if (r_fold) {
+            // dy = gamma*is*(g - m1 - xhat*m2), xhat = (u - mu)*is  ==  A g + B u + D   (coefficients formed in fp64)
+            double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += braw.s[2 * q]; s2 += braw.s[2 * q + 1]; b1 += fs1[q]; b2 += fs2[q]; }
+            const double cnt = (double)M, mu = s1 / cnt;
+            double var = s2 / cnt - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double is = 1.0 / sqrt(var + (double)braw.eps), gi = (double)braw.g * is;
+            const double m1 = b1 / cnt, m2 = b2 / cnt;
+            s_fold[tid] = (float)gi;
+            s_fold[C + tid] = (float)(-gi * is * m2);
+            s_fold[2 * C + tid] = (float)(gi * (mu * is * m2 - m1));
+            if (bi == 0 && n0 == 0) {                     // the affine parameters' gradients fall out of the two sums
+                if (a.fold_dgamma != nullptr) a.fold_dgamma[tid] = (float)b2;
+                if (a.fold_dbeta != nullptr) a.fold_dbeta[tid] = (float)b1;
+            }
         } else if (r_epi) {
             float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
             if (n0 + te < K) bn_resolve(braw, (double)M, sc, sh, mu, is);
@@ -415,7 +472,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     // =========================== the tile loop ===========================
     // Weight fragment of (tap, kk): row hc*32 + l31 of tile `tap`, 16-byte chunk (2 kk + hh) ^ sw(row); sw(l31 + 32) == sw(l31).
     for (int tile = t_beg; tile < t_end; ++tile) {
-        halo_store();                                     // BN+ReLU on the way into the operand image (waits for the tile's rows)
+        halo_store(tile);                                 // BN+ReLU / folded BN-backward apply on the way into the operand image
         if (tile + 1 < t_end) halo_load(tile + 1);        // in flight during this tile's MFMAs and epilogue
         if (res != nullptr || BWD) request(tile);
         tile_addr(tile);
@@ -603,7 +660,7 @@ __global__ __launch_bounds__(512, BWD ? 2 : 4) void conv_pp_kernel(const PPArgs 
 constexpr size_t PP_LDS_MAX = 160 * 1024;
 
 // FPD_CONV_PP: 0 = never, 1 = launches with >= FPD_CONV_PP_MIN_TILES (256) pixel tiles (default), 2 = whenever the shape is in
-// the domain; FPD_CONV_PP_BLOCKS: persistent blocks per occupancy slot (default 128: the grid is that times the blocks a CU can
+// the domain; FPD_CONV_PP_BLOCKS: persistent blocks per occupancy slot (default 256 (128 until the teacher wait moved in front of the loss): the grid is that times the blocks a CU can
 // hold, at most 2 -- r03 sweep inside the pipelined step, one box: 64/96/128/256 x 2 -> 12.38/11.41/11.00/11.01 ms, 128/192/256 x 1
 // -> 11.35/11.12/11.03; threshold 512/256/128 tiles -> 11.00/10.79/10.78; conv_tile only: 11.50).  mode / blocks can be changed
 // at run time through fpd_set_option("conv_pp" / "conv_pp_blocks", v) (tests drive small shapes through the kernel that way).
@@ -613,7 +670,7 @@ static int pp_mode() {
     return g_pp_mode;
 }
 static int pp_blocks() {
-    if (g_pp_blocks < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS"); g_pp_blocks = e ? atoi(e) : 128; }
+    if (g_pp_blocks < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS"); g_pp_blocks = e ? atoi(e) : 256; }
     return g_pp_blocks < 1 ? 1 : g_pp_blocks;
 }
 static int pp_min_tiles() {  // FPD_CONV_PP_MIN_TILES: smallest launch (pixel tiles) the kernel takes in mode 1
@@ -686,7 +743,7 @@ static bool pp_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, PPPl
         region = std::max(img(a, pl.ga), b ? img(*b, pl.gb) : 0);
     }
     pl.ga.region = pl.gb.region = region;
-    pl.lds = (size_t)(2 * a.C + 5 * 32 * KH) * sizeof(float) + (size_t)a.R * a.R * 32 * KH * a.C * 2 + (size_t)region;
+    pl.lds = (size_t)(2 * a.C + 5 * 32 * KH + (bwd ? 3 * a.C : 0)) * sizeof(float) + (size_t)a.R * a.R * 32 * KH * a.C * 2 + (size_t)region;
     if (pl.wg) pl.lds += (size_t)8 * 32 * (32 * 4 + 16) + (size_t)(256 / KH) * (32 * KH * 2 + 16);
 #ifdef FPD_PP_TIMING
     pl.lds += 1024;
@@ -790,6 +847,14 @@ int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_
 
 // slabs of the fused weight gradient (fpd_conv_t.wg_partial) for a single launch / the two halves of a pair launch; 0 = the
 // launch would not run here, or not with the fusion
+// 1 if the launch (pair) is served by this kernel as a BNRELU_BWD data gradient without a prologue BN: the configuration in which
+// a folded BN-backward apply (fpd_conv_t.fold_x) is evaluated on the way into the operand image
+int fpd_conv_pp_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b) {
+    if (a.epi != FPD_EPI_BNRELU_BWD || a.bn.mode != FPD_BN_NONE) return 0;
+    if (b != nullptr && (b->epi != FPD_EPI_BNRELU_BWD || b->bn.mode != FPD_BN_NONE)) return 0;
+    return pp_takes(a, b) ? 1 : 0;
+}
+
 int fpd_conv_pp_wgrad_partials(const fpd_conv_t& a) {
     PPPlan pl;
     if (!pp_takes(a, nullptr) || !pp_plan(a, nullptr, true, pl) || !pl.wg) return 0;

@@ -132,11 +132,50 @@ class Lowering:
             n = R.lib().fpd_conv_fused_wgrad_partials(C.byref(s))
             if n > 0:
                 self._fuse_wgrad(op, s, n)
+        if not plain:
+            self._fill_fold(op, s)
         if getattr(op, 'w8', None) is not None and not plain:
             f = R.ConvF8T()
             f.c, f.w8, f.w8_scale = s, p(op.w8), p(op.w8s)
             return R.OP_CONV_F8, f
         return R.OP_CONV, s
+
+    def plan_folds(self, ops):
+        """Decide, BEFORE the list is lowered, which BN-backward applies are evaluated by the data gradient that consumes
+        them (graph: conv.fold_apply; include/fpd_amd.h: fpd_conv_t.fold_x): where the library serves the launch (pair)
+        that way the apply is marked `folded` (lowered as a no-op) and the convolution `fold_active`."""
+        if os.environ.get('FPD_FOLD_APPLY', '1') == '0':
+            return
+        l = R.lib()
+        for op in ops:
+            if op is None or op.kind not in ('conv', 'conv2'):
+                continue
+            members = [m for m in ((op.a, op.b) if op.kind == 'conv2' else (op,)) if m is not None]
+            cands = [m for m in members if getattr(m, 'fold_apply', None) is not None and not getattr(m.fold_apply, 'folded', False)]
+            if not cands or any(getattr(m, 'w8', None) is not None for m in members):
+                continue
+            if op.kind == 'conv2':
+                ps = R.ConvPairT()
+                ps.a, ps.b = self.conv(op.a, plain=True)[1], self.conv(op.b, plain=True)[1]
+                ok = l.fpd_conv_pair_fold_supported(C.byref(ps)) == 1
+            else:
+                ok = l.fpd_conv_fold_supported(C.byref(self.conv(op, plain=True)[1])) == 1
+            if ok:
+                for m in cands:
+                    m.fold_active = True
+                    m.fold_apply.folded = True
+
+    def _fill_fold(self, op, s):
+        """Fold fields of a data gradient that evaluates its BN-backward apply itself (plan_folds decided)."""
+        if not getattr(op, 'fold_active', False):
+            return
+        ap, p = op.fold_apply, self.A.ptr
+        assert ap.add is None and _abuf(ap.y) is _abuf(op.x), 'fold: the apply must produce exactly this operand'
+        s.x = p(_abuf(ap.dy))                               # the masked gradient; the operand proper is evaluated in-kernel
+        s.fold_x, s.fold_bn, s.fold_stats = p(_abuf(ap.x)), self.bn(ap.bn), p(ap.bstats)
+        s.fold_dgamma, s.fold_dbeta = p(ap.dgamma), p(ap.dbeta)
+        # its other consumer -- the convolution's weight gradient -- reads the evaluated operand unless it is formed right here
+        s.fold_out = None if getattr(op, 'fused_active', False) else p(_abuf(ap.y))
 
     def _fuse_wgrad(self, op, s, n):
         """The data-gradient launch `op` (struct `s`, a ConvT -- possibly a field of a pair struct) also forms the weight
@@ -267,6 +306,8 @@ class Lowering:
         return R.OP_STEM_WGRAD, s
 
     def ew(self, op):
+        if getattr(op, 'folded', False):                   # evaluated by the data gradient that consumes it (plan_folds)
+            return R.OP_NOP, R.MemsetT()
         s = R.EwT()
         s.op, s.dtype = _EW[op.op], self.dtype
         (s.N, s.H, s.W, s.C) = op.dims
@@ -326,8 +367,13 @@ class Lowering:
                 if na.value > 0 and nb.value > 0:          # s.a / s.b are views INTO the pair struct: patched in place later
                     self._fuse_wgrad(op.a, s.a, na.value)
                     self._fuse_wgrad(op.b, s.b, nb.value)
+            self._fill_fold(op.a, s.a)
+            self._fill_fold(op.b, s.b)
             return R.OP_CONV_PAIR, s
         if op.kind == 'ew2':
+            fa, fb = getattr(op.a, 'folded', False), getattr(op.b, 'folded', False)
+            if fa or fb:                                   # folded members leave the pair
+                return (R.OP_NOP, R.MemsetT()) if (fa and fb) else self.ew(op.b if fa else op.a)
             s = R.EwPairT()
             s.a, s.b = self.ew(op.a)[1], self.ew(op.b)[1]
             return R.OP_EW_PAIR, s
@@ -486,6 +532,7 @@ class GraphInstance:
             p.add(*self.low.memset('grad'))
             self.low.use_partials = True
             bwd_ir = [op for op in g.bwd if op.kind != 'seed']
+            self.low.plan_folds(bwd_ir)
             lowered = [self.low.op(op) for op in bwd_ir]
             self.low.finish_partials()                # patches the wgrad structs / fills the per-bucket reduce tables
             self.bucket_ops = {}                      # gradient bucket -> plan op after which its grad slice is final

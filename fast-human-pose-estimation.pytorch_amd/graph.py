@@ -24,6 +24,7 @@ STATS_REPLICAS = int(os.environ.get('FPD_STATS_REPLICAS', '4'))   # include/fpd_
 # LANE_LEVELS largest resolutions get a lane, and weight gradients are issued in batches of WGRAD_BATCH on one lane.
 WGRAD_LANES = 1
 LANE_LEVELS = 0
+FOLD_APPLY = os.environ.get('FPD_FOLD_APPLY', '1') != '0'     # BN-backward applies evaluated by the consuming data gradient where the library offers it
 WREDUCE_PER_BATCH = os.environ.get('FPD_WREDUCE_PER_BATCH', '0') == '1'   # slab reduction per weight-gradient batch instead of once per gradient bucket (measured equal: 10.67 vs 10.67 ms, 22 more launches)
 WGRAD_BATCH = 8     # re-swept in round 2 on one box: 1/2/4/8/12/16/24/32 -> 11.92/11.83/11.69/11.67/11.81/11.83/11.90/11.99 ms (the lane tail before Adam)
 
@@ -48,7 +49,7 @@ class Buf:
 
 class Act:
     """NHWC activation (or activation-gradient) tensor; `buf` is assigned by plan_memory()."""
-    __slots__ = ('shape', 'buf', 'stats', 'producer', 'grad', 'name', 'persistent', 'needs_grad')
+    __slots__ = ('shape', 'buf', 'stats', 'producer', 'grad', 'name', 'persistent', 'needs_grad', 'apply_op')
 
     def __init__(self, shape, name=''):
         self.shape = tuple(shape)      # (N,H,W,C)
@@ -59,6 +60,7 @@ class Act:
         self.name = name
         self.persistent = False
         self.needs_grad = True
+        self.apply_op = None           # gradient tensors: the BN-backward apply whose sole result this is (or None)
 
     @property
     def numel(self):
@@ -116,6 +118,10 @@ class Op:
             fw = getattr(self, 'fused_wgrad', None)        # this data gradient also writes the slabs of that weight gradient
             if fw is not None and getattr(self, 'fused_active', False):
                 wr += [fw.dw, fw.dbias]
+            fa = getattr(self, 'fold_apply', None)         # it may evaluate that BN-backward apply itself (executor decides):
+            if fa is not None:                             # then it reads the apply's inputs and writes its outputs
+                rd += [b(fa.x), b(fa.dy), fa.bstats] + bn_bufs(fa.bn)
+                wr += [b(fa.y), fa.dgamma, fa.dbeta]
         elif k == 'head':
             rd = [b(self.y0), b(self.x), self.w_fc, self.b_fc, self.w_score, self.b_score, self.w_fc2, self.b_fc2,
                   self.w_score2, self.b_score2] + bn_bufs(self.bn)
@@ -154,8 +160,10 @@ class Op:
             return self.a.acts_in() + self.b.acts_in()
         if self.kind == 'head':
             return [t for t in (self.y0, self.x) if t is not None]
+        fa = getattr(self, 'fold_apply', None)
+        folded = [t for t in (fa.x, fa.dy) if isinstance(t, Act)] if fa is not None else []
         return [getattr(self, f) for f in ('x', 'x2', 'dy', 'add', 'residual', 'epi_x') if
-                isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None]
+                isinstance(getattr(self, f, None), Act)] + [a for a in getattr(self, 'extra_in', []) if a is not None] + folded
 
     def acts_out(self):
         if self.kind in ('conv2', 'bneck2', 'ew2'):
@@ -635,6 +643,8 @@ class HourglassGraph:
             apply = Op('ew', op='bn_bwd_apply', dims=x.shape, x=x, x2=None, dy=pend['dz'], add=add, y=out,
                        out_stats=None, bstats=bstats, dgamma=self.p.grad(bn.name + '.weight'),
                        dbeta=self.p.grad(bn.name + '.bias'), bn=bn, lane=self._home(x))
+            if add is None:
+                out.apply_op = apply            # `out` is exactly this apply's result: its consumer may evaluate it itself
             c = self._pair_ew
             if c is None or (apply.lane or 0) != 0:
                 self.bwd.append(apply)
@@ -783,6 +793,13 @@ class HourglassGraph:
                 # issued, the slabs of a later launch would never be summed)
                 if R == 1 and stride == 1 and dy is op.y.grad and any(w is wg for w in self._wg_pending):
                     d.fused_wgrad = wg
+                # dy itself is the output of a BN-backward apply and nothing else reads it but this convolution's data and
+                # weight gradient: the data gradient may evaluate the apply on its operand load (fpd_conv_t.fold_x) and the
+                # separate launch becomes a no-op -- decided at lowering time like the fused weight gradient
+                ap = getattr(op.y.grad, 'apply_op', None)
+                if FOLD_APPLY and ap is not None and stride == 1 and dy is op.y.grad and (ap.lane or 0) == (d.lane or 0):
+                    d.fold_apply = ap
+                    d.fold_wgrad = wg
                 self._emit_dgrad(d)
             self._bn_backward_contribution(x, op.bn, make)
         else:

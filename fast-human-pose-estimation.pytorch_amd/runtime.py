@@ -35,7 +35,8 @@ class ConvT(C.Structure):
                 ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('epi', _i32),
                 ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('residual', _vp), ('y', _vp),
                 ('out_stats', _vp), ('bn', BnT), ('epi_x', _vp), ('epi_bn', BnT), ('epi_stats', _vp),
-                ('wg_partial', _vp), ('wg_stride', _i64), ('wg_bias', _i32), ('_pad2', _i32)]
+                ('wg_partial', _vp), ('wg_stride', _i64), ('wg_bias', _i32), ('_pad2', _i32),
+                ('fold_x', _vp), ('fold_bn', BnT), ('fold_stats', _vp), ('fold_out', _vp), ('fold_dgamma', _vp), ('fold_dbeta', _vp)]
 
 
 class ConvF8T(C.Structure):
@@ -183,6 +184,8 @@ SYMBOLS = {
     'fpd_bottleneck_fold': (C.c_int, [C.POINTER(BneckT), _vp]),
     'fpd_bottleneck_forward_pair': (C.c_int, [C.POINTER(BneckPairT), _vp]),
     'fpd_conv_fused_wgrad_partials': (C.c_int, [C.POINTER(ConvT)]),
+    'fpd_conv_fold_supported': (C.c_int, [_vp]),
+    'fpd_conv_pair_fold_supported': (C.c_int, [_vp]),
     'fpd_conv_pair_fused_wgrad_partials': (C.c_int, [C.POINTER(ConvPairT), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'fpd_conv_wgrad': (C.c_int, [C.POINTER(WgradT), _vp]),
     'fpd_wgrad_num_partials': (C.c_int, [C.POINTER(WgradT)]),

@@ -91,6 +91,20 @@ typedef struct {
     int64_t wg_stride;     /* floats between slabs, >= C*K + C */
     int32_t wg_bias;       /* also accumulate the bias gradient */
     int32_t _pad2;
+    /* FOLDED BN-BACKWARD APPLY (optional; BNRELU_BWD data gradients served by the persistent kernel only, bn.mode NONE): x is
+     * not the operand itself but the masked gradient g that reached a train-mode BatchNorm whose input was fold_x = u, with
+     * the two sums {sum g, sum g*xhat} in fold_stats.  The launch evaluates the BN backward on the way into its operand image,
+     *     dy = gamma*invstd * (g - mean(g) - xhat*mean(g*xhat)),   xhat = (u - mean(u)) * invstd,
+     * rounds it once (like the stand-alone FPD_EW_BN_BWD_APPLY it replaces: one launch and three tensor passes fewer) and
+     * convolves THAT; if fold_out is given the evaluated operand is also written out once ([N,H,W,C], for a separate
+     * weight-gradient launch), fold_dgamma / fold_dbeta receive sum g*xhat / sum g.  fpd_conv_fold_supported() tells
+     * whether a launch is served (0: leave fold_x NULL and issue the apply). */
+    const void* fold_x;
+    fpd_bn_t fold_bn;
+    const double* fold_stats;
+    void* fold_out;
+    float* fold_dgamma;
+    float* fold_dbeta;
 } fpd_conv_t;
 
 /* A whole pre-activation Bottleneck of a FROZEN network in one launch (hourglass.py:32-52 with eval-mode BN, no
@@ -307,6 +321,10 @@ int fpd_bottleneck_forward_pair(const fpd_bneck_pair_t* p, fpd_stream_t stream);
 /* slabs the fused weight gradient of data-gradient launch `a` writes (see fpd_conv_t.wg_partial); 0 = not available.  For the
  * two convolutions of a pair launch: fpd_conv_pair_fused_wgrad_partials (counts for p->a and p->b; returns 0 / error code). */
 int fpd_conv_fused_wgrad_partials(const fpd_conv_t* a);
+/* 1 if fpd_conv_forward() / fpd_conv_forward_pair() would serve these launches WITH a folded BN-backward apply (fold_x set
+ * or not: only the dimensions, epilogue and prologue are looked at); 0 otherwise. */
+int fpd_conv_fold_supported(const fpd_conv_t* a);
+int fpd_conv_pair_fold_supported(const fpd_conv_pair_t* p);
 int fpd_conv_pair_fused_wgrad_partials(const fpd_conv_pair_t* p, int32_t* n_a, int32_t* n_b);
 int fpd_conv_wgrad(const fpd_wgrad_t* a, fpd_stream_t stream);
 int fpd_wgrad_num_partials(const fpd_wgrad_t* a);   /* slabs fpd_conv_wgrad writes when a->partial is set */
@@ -495,7 +513,7 @@ const char* fpd_last_error(void);
 int fpd_set_backend(int32_t backend);         /* FPD_BACKEND_*; returns previous */
 /* run-time knobs (process-wide; the defaults are what the product uses): "conv_pp" = 0 never / 1 launches with >= 256 pixel
  * tiles (default) / 2 whenever in its domain: use of the persistent convolution kernel for big maps (csrc/conv_pp.hip);
- * "conv_pp_blocks" = its persistent blocks per occupancy slot (default 128); "wgrad_tile_only" = 1: fpd_conv_wgrad() fails
+ * "conv_pp_blocks" = its persistent blocks per occupancy slot (default 256); "wgrad_tile_only" = 1: fpd_conv_wgrad() fails
  * instead of falling through to the generic kernels when the halo-tile kernel declines a shape (tests).  Returns the
  * previous value (>= 0; 0 for "wgrad_tile_only"), negative = unknown option. */
 int fpd_set_option(const char* name, int32_t value);

@@ -79,6 +79,8 @@ class Bench:
         plan = R.Plan()
         prev = R.set_backend(backend)
         low.use_partials = partials          # two-stage weight-gradient reduction (slabs + fpd_wgrad_reduce)
+        low.plan_folds([o for o in ops if o.kind != 'wprep'])      # BN-backward applies evaluated by their consumer
+        self.n_folded = sum(1 for o in ops if getattr(o, 'folded', False))
         lowered = []
         for op in ops:
             if op.kind == 'wprep':
@@ -296,6 +298,72 @@ def test_conv_pp_dgrad_with_fused_weight_gradient(case):
     bt.compare(dw, label='fused wgrad dw %s' % (case,), **tol)
     if bias:
         bt.compare(db, label='fused wgrad dbias', **tol)
+
+
+FOLD_CASES = [(4, 64, 64, 128, 64, 1, 8, True), (4, 64, 64, 64, 128, 1, 8, False), (2, 64, 64, 64, 64, 3, 5, False),
+              (1, 128, 128, 32, 32, 3, 6, False), (3, 20, 48, 64, 32, 1, 3, True), (2, 32, 32, 64, 64, 3, 4, False),
+              (2, 32, 32, 128, 64, 1, 4, True)]
+
+
+@pytest.mark.parametrize('case', FOLD_CASES)
+def test_conv_pp_dgrad_with_folded_bn_backward_apply(case):
+    """A data gradient whose operand is the output of a BN-backward apply evaluates the apply itself on its operand load
+    (fpd_conv_t.fold_x): the stand-alone apply must become a no-op and everything downstream -- the data gradient with its
+    ReLU mask and sums, the convolution's weight / bias gradient (fused into the launch for 1x1, a separate launch reading
+    the materialised operand for 3x3), the BN's dgamma / dbeta -- must match the specification of the un-folded op list."""
+    N, H, W, C, K, Rr, blocks, bias = case                # forward convolution u = conv(a(x)), C -> K, then bn_next(u)
+    pad = (Rr - 1) // 2
+    gen = torch.Generator().manual_seed(53 + sum(case[:7]))
+    bt = Bench(1)
+    x_val = rnd(gen, N, H, W, C)
+    x = bt.act((N, H, W, C), x_val, 'x')                  # forward input of the convolution (pre BN+ReLU)
+    u_val = rnd(gen, N, H, W, K)
+    u = bt.act((N, H, W, K), u_val, 'u')                  # its output = input of the next BN
+    g_val = rnd(gen, N, H, W, K, scale=0.1)
+    g = bt.act((N, H, W, K), g_val, 'g')                  # masked gradient that reached that BN
+    wm = bt.buf('param', (K, Rr, Rr, C), rnd(gen, K, Rr, Rr, C, scale=1.0 / np.sqrt(C * Rr * Rr)))
+    wb = bt.buf('wlp', (C, Rr, Rr, K))
+    du = bt.act((N, H, W, K), None, 'du')
+    dz = bt.act((N, H, W, C), None, 'dz')
+    bn = make_bn(bt, gen, C, 'train')                     # BN in front of the convolution (mask + sums of the data gradient)
+    bn.count = N * H * W
+    bn.stats = bt.buf('stats', (RS, 2, C), tensor_stats(x_val.to(torch.bfloat16).float()))
+    bn2 = make_bn(bt, gen, K, 'train')                    # the BN whose backward is folded
+    bn2.count = N * H * W
+    bn2.stats = bt.buf('stats', (RS, 2, K), tensor_stats(u_val.to(torch.bfloat16).float()))
+    gq, uq = g_val.to(torch.bfloat16).float(), u_val.to(torch.bfloat16).float()
+    mean, var = uq.mean((0, 1, 2)), uq.var((0, 1, 2), unbiased=False)
+    xhat = (uq - mean) / torch.sqrt(var + 1e-5)
+    sums = torch.zeros(RS, 2, K, dtype=torch.float64)
+    sums[0, 0], sums[0, 1] = gq.double().sum((0, 1, 2)), (gq.double() * xhat.double()).sum((0, 1, 2))
+    bst2 = bt.buf('stats', (RS, 2, K), sums)
+    dgam, dbet = bt.buf('grad', (K,), torch.zeros(K)), bt.buf('grad', (K,), torch.zeros(K))
+    bst = bt.buf('stats', (RS, 2, C), torch.zeros(RS, 2, C, dtype=torch.float64))
+    dw = bt.buf('grad', (K, Rr, Rr, C), torch.zeros(K, Rr, Rr, C))
+    db = bt.buf('grad', (K,), torch.zeros(K)) if bias else None
+    ap = G.Op('ew', op='bn_bwd_apply', dims=(N, H, W, K), x=u, x2=None, dy=g, add=None, y=du, out_stats=None, bstats=bst2,
+              dgamma=dgam, dbeta=dbet, bn=bn2)
+    wg = G.Op('wgrad', x=x, dy=du, dw=dw, dbias=db, bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, H, W))
+    dg = G.Op('conv', x=du, w=wb, wkey='w', bias=None, bkey=None, residual=None, y=dz, out_stats=None, bn=None,
+              epi='bnrelu_bwd', epi_x=x, epi_bn=bn, epi_stats=bst, dims=(N, H, W, K, C, Rr, Rr, 1, Rr - 1 - pad, H, W))
+    dg.fold_apply, dg.fold_wgrad = ap, wg
+    if Rr == 1:
+        dg.fused_wgrad = wg
+    ops = [G.Op('wprep', entries=[{'w': wm, 'w_fwd': None, 'w_bwd': wb}]), ap, dg, wg]
+    bt.realise().run(ops, ('pp', blocks), partials=True)
+    assert bt.n_folded == 1 and getattr(dg, 'fold_active', False), 'the BN-backward apply was not folded into the data gradient'
+    assert (bt.n_fused == 1) == (Rr == 1)
+    bt.compare(dz, label='folded dgrad dz %s' % (case,), **TOL[1])
+    bt.compare(bst, atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='folded dgrad bn sums')
+    bt.compare(dgam, atol=1e-3, rtol=1e-4, label='dgamma of the folded BN')
+    bt.compare(dbet, atol=1e-3, rtol=1e-4, label='dbeta of the folded BN')
+    m = N * H * W
+    tol = dict(atol=2e-2 + 2e-5 * m, rtol=3e-2)
+    bt.compare(dw, label='wgrad dw behind the fold %s' % (case,), **tol)
+    if bias:
+        bt.compare(db, label='wgrad dbias behind the fold', **tol)
+    if Rr == 3:                                           # the operand was materialised for the separate weight-gradient launch
+        bt.compare(du, label='materialised operand', **TOL[1])
 
 
 def test_conv_pp_equals_conv_tile_bitwise():
