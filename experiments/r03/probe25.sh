@@ -2,7 +2,7 @@
 # round-3 probe 25: BN-backward applies folded into the consuming data gradient (FPD_FOLD_APPLY=1, default) vs not
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/r03p25; mkdir -p $O
-( timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -x -k "folded or conv_pp or pair or dgrad" > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log ); tail -5 $O/tests.log | cut -c1-300
+( timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -x -k "folded or conv_pp or pair or dgrad or conv_forward" > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log ); tail -5 $O/tests.log | cut -c1-300
 ( timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider -x > $O/tests_model.log 2>&1; echo "rc=$?" >> $O/tests_model.log ); tail -5 $O/tests_model.log | cut -c1-300
 run() {  # name, env
   timeout 200 env $2 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2> $O/$1.err | grep '^{' > $O/$1.json

@@ -14,6 +14,8 @@ int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_conv_pp_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b);
+int fpd_conv_tile_fold_ok(const fpd_conv_t& a);
+int fpd_conv_tile_pair_fold_ok(const fpd_conv_t& a, const fpd_conv_t& b);
 int fpd_conv_pp_option(int which, int value);
 int fpd_conv_pp_wgrad_partials(const fpd_conv_t& a);
 int fpd_conv_pp_pair_wgrad_partials(const fpd_conv_t& a, const fpd_conv_t& b, int* na, int* nb);
@@ -133,9 +135,9 @@ static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent kernel
     FPD_REQUIRE(rc != 1 || a->wg_partial == nullptr, "conv: a fused weight gradient (wg_partial) needs the persistent kernel; "
                 "fpd_conv_fused_wgrad_partials() reports 0 for this launch");
-    FPD_REQUIRE(rc != 1 || a->fold_x == nullptr, "conv: a folded BN-backward apply (fold_x) needs the persistent kernel; "
-                "fpd_conv_fold_supported() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
+    FPD_REQUIRE(rc != 1 || a->fold_x == nullptr, "conv: a folded BN-backward apply (fold_x) needs the persistent or the halo-tile "
+                "kernel; fpd_conv_fold_supported() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_mfma_launch(*a, st);
     if (rc == 1 && g_fpd_backend != FPD_BACKEND_NAIVE) rc = fpd_conv_smallc_launch(*a, st);   // tiny input-channel counts (3, 17)
     if (rc == 1) rc = fpd_conv_naive_launch(*a, st);
@@ -151,11 +153,15 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
 
 int fpd_conv_fold_supported(const fpd_conv_t* a) {
     if (!a || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(a) != 0) return 0;
-    return fpd_conv_pp_fold_ok(*a, nullptr);
+    return (fpd_conv_pp_fold_ok(*a, nullptr) || fpd_conv_tile_fold_ok(*a)) ? 1 : 0;
 }
 int fpd_conv_pair_fold_supported(const fpd_conv_pair_t* p) {
     if (!p || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(&p->a) != 0 || validate_conv(&p->b) != 0) return 0;
-    return fpd_conv_pp_fold_ok(p->a, &p->b);
+    // the dispatch order of fpd_conv_forward_pair(): persistent pair, halo-tile pair, two single launches
+    if (fpd_conv_pp_fold_ok(p->a, &p->b)) return 1;
+    const int r = fpd_conv_tile_pair_fold_ok(p->a, p->b);
+    if (r >= 0) return r;
+    return (fpd_conv_fold_supported(&p->a) && fpd_conv_fold_supported(&p->b)) ? 1 : 0;
 }
 
 int fpd_conv_fused_wgrad_partials(const fpd_conv_t* a) {
@@ -203,8 +209,6 @@ int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
     FPD_REQUIRE(rc != 1 || (p->a.wg_partial == nullptr && p->b.wg_partial == nullptr),
                 "conv_pair: fused weight gradients need the persistent kernel; fpd_conv_pair_fused_wgrad_partials() reports 0 for this launch");
-    FPD_REQUIRE(rc != 1 || (p->a.fold_x == nullptr && p->b.fold_x == nullptr),
-                "conv pair: a folded BN-backward apply (fold_x) needs the persistent kernel");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);
     if (rc == 1) {                       // not pairable: same result from two launches
         rc = dispatch_conv(&p->a, st);

@@ -72,7 +72,7 @@ static inline unsigned magic_of(int d) { return (unsigned)((0x100000000ull / (un
 // ALLW (3x3, one channel chunk, grids that do not fill the chip): the weights of ALL nine taps are staged up front, so the
 // MFMA loop runs its 9 taps back to back behind ONE barrier instead of one barrier (and one exposed weight-load latency) per
 // tap -- these launches are latency-bound, LDS capacity is not a constraint for them.
-template <typename T, int TN, int BK, bool ALLW = false>
+template <typename T, int TN, int BK, bool ALLW = false, bool FOLD = false>
 __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGeo geo, const int dbg, const int bx, const int by) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
@@ -96,12 +96,19 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     float* s_scale = reinterpret_cast<float*>(smem);
     float* s_shift = s_scale + C;
     float* s_epi = s_shift + C;
-    T* sH = reinterpret_cast<T*>(s_epi + 4 * BNT);
+    // FOLDED BN-BACKWARD APPLY (fpd_conv_t.fold_x, BNRELU_BWD data gradients without a prologue BN): the operand proper is
+    // dy = A_c g + B_c u + D_c (g = x, u = fold_x), evaluated on the way into the halo tile and rounded once
+    const bool bwd_epi = a.epi == FPD_EPI_BNRELU_BWD;
+    const bool fold = FOLD && bwd_epi && a.fold_x != nullptr;      // FOLD: compiled in for TN <= 2 only (register budget)
+    float* s_fold = s_epi + 4 * BNT;                      // [3][C] when the epilogue is BNRELU_BWD
+    T* sH = reinterpret_cast<T*>(s_fold + (bwd_epi ? 3 * C : 0));
     T* sB = sH + HP * LD;
     float* stage = reinterpret_cast<float*>(sH);         // epilogue staging tile (after the last MFMA)
     double* s_red = reinterpret_cast<double*>(sH);
     const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+    const T* __restrict__ fx = reinterpret_cast<const T*>(a.fold_x);
+    T* fo = (fold && by == 0) ? reinterpret_cast<T*>(a.fold_out) : nullptr;       // written once: by the first channel tile
 
     // ---- per-lane A addressing: output pixel -> halo row/col; invalid tap rows point at the zero pixels ----
     const int ml = wave * 32 + (lane & 31);
@@ -123,7 +130,7 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     // ---- staging registers ----
     const int nvtot = hrows * W * VPR;
     const int WV = W * VPR;
-    uint4 rh[NVH];
+    uint4 rh[NVH], ru[FOLD ? NVH : 1];           // ru: the same vectors of u (fold)
     unsigned hmask = 0;
     auto halo_load = [&](int c0) {
         hmask = 0;
@@ -138,6 +145,7 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
                 const int g = g0 - pad + hr;
                 if ((unsigned)g < (unsigned)GR) {
                     rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(g * W + j) * C + c0 + cv));
+                    if (FOLD && fold) ru[i] = *reinterpret_cast<const uint4*>(fx + ((size_t)(g * W + j) * C + c0 + cv));
                     hmask |= 1u << i;
                 }
             }
@@ -152,6 +160,13 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { psc[e] = s_scale[c0 + cvh + e]; psh[e] = s_shift[c0 + cvh + e]; }
         }
+        float pfa[VEC], pfb[VEC], pfd[VEC];
+        if (FOLD && fold) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                pfa[e] = s_fold[c0 + cvh + e]; pfb[e] = s_fold[C + c0 + cvh + e]; pfd[e] = s_fold[2 * C + c0 + cvh + e];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             const int v = tid + i * 256;
@@ -159,6 +174,19 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
                 const int hr = qdiv(v, geo.mWV);
                 const int j = (v - hr * WV) >> LOG_VPR;
                 uint4 val = rh[i];
+                if (FOLD && fold) {
+                    const bool in = (hmask >> i) & 1u;
+                    float g[VEC], u[VEC];
+                    DT<T>::unpack(val, g);
+                    DT<T>::unpack(in ? ru[i] : make_uint4(0, 0, 0, 0), u);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[e] = fmaf(pfa[e], g[e], fmaf(pfb[e], u[e], pfd[e]));
+                    val = DT<T>::pack(g);
+                    if (!in) val = make_uint4(0, 0, 0, 0);                         // rows outside the tensor stay exactly zero
+                    // written out once for the operand's other consumer (a separate weight-gradient launch): rows of this tile only
+                    if (fo != nullptr && in && hr >= pad && hr < pad + nrows)
+                        *reinterpret_cast<uint4*>(fo + ((size_t)((g0 - pad + hr) * W + j) * C + c0 + cvh)) = val;
+                }
                 if (a.bn.mode != FPD_BN_NONE) {
                     float f[VEC];
                     DT<T>::unpack(val, f);
@@ -239,6 +267,30 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
         }
     }
     if (!(dbg & 8)) bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    if (FOLD && fold) {
+        // dy = gamma*is*(g - m1 - xhat*m2), xhat = (u - mu)*is  ==  A g + B u + D   (coefficients formed in fp64);
+        // the upper half of the block does it while the lower half fills the epilogue tables
+        for (int c = tid - 128; c >= 0 && c < C; c += 128) {
+            BnRaw r;
+            bn_request(a.fold_bn, c, C, r);
+            const double b1 = stats_sum(a.fold_stats, C, c), b2 = stats_sum(a.fold_stats, C, C + c);
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += r.s[2 * q]; s2 += r.s[2 * q + 1]; }
+            const double cnt = (double)M, mu = s1 / cnt;
+            double var = s2 / cnt - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double is = 1.0 / sqrt(var + (double)r.eps), gi = (double)r.g * is;
+            const double m1 = b1 / cnt, m2 = b2 / cnt;
+            s_fold[c] = (float)gi;
+            s_fold[C + c] = (float)(-gi * is * m2);
+            s_fold[2 * C + c] = (float)(gi * (mu * is * m2 - m1));
+            if (bx == 0 && by == 0) {                     // the affine parameters' gradients fall out of the two sums
+                if (a.fold_dgamma != nullptr) a.fold_dgamma[c] = (float)b2;
+                if (a.fold_dbeta != nullptr) a.fold_dbeta[c] = (float)b1;
+            }
+        }
+    }
     conv_epi_tables<BNT>(a, n0, M, s_epi);
 
     if constexpr (ALLW) {
@@ -286,22 +338,22 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     }
 }
 
-template <typename T, int TN, int BK, bool ALLW>
+template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo, const int dbg) {
-    conv_tile_body<T, TN, BK, ALLW>(a, geo, dbg, blockIdx.x, blockIdx.y);
+    conv_tile_body<T, TN, BK, ALLW, FOLD>(a, geo, dbg, blockIdx.x, blockIdx.y);
 }
 
 // Two INDEPENDENT convolutions with the same tile configuration in one launch: pixel tiles [0, nbx_a) belong to `a`,
 // the rest to `b` (block-uniform choice; the descriptors live in kernel-argument memory).  Used for the two parallel
 // bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
-template <typename T, int TN, int BK, bool ALLW>
+template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const TileGeo logWa,
                                                                 const TileGeo logWb, const int nbx_a, const int dbg) {
     // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
     // launch ends with a's normal tail instead of a's tail followed by b's
     const int nbx_b = (int)gridDim.x - nbx_a;
-    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK, ALLW>(b, logWb, dbg, blockIdx.x, blockIdx.y);
-    else conv_tile_body<T, TN, BK, ALLW>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
+    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK, ALLW, FOLD>(b, logWb, dbg, blockIdx.x, blockIdx.y);
+    else conv_tile_body<T, TN, BK, ALLW, FOLD>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
 }
 
 // FPD_CONV_ALLW: largest grid (blocks) that uses the all-taps-staged variant; 0 disables it
@@ -337,7 +389,7 @@ static size_t tile_lds(const fpd_conv_t& c) {
 template <typename T, int TN, int BK, bool ALLW>
 int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
-    const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
+    const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN + (a.epi == FPD_EPI_BNRELU_BWD ? 3 * a.C : 0)) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
     if (lds > LDS_MAX) return 1;
     static size_t configured = 0;
     if (lds > configured) {
@@ -351,6 +403,20 @@ int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     static const int edbg = getenv("FPD_EPI_DBG") ? atoi(getenv("FPD_EPI_DBG")) : 0;    // epilogue ablation bits, travel in a._pad
     fpd_conv_t ac = a;
     ac._pad = edbg;
+    if constexpr (TN <= 2) {
+        if (a.fold_x != nullptr) {
+            static size_t configured_f = 0;
+            if (lds > configured_f) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+                configured_f = lds;
+            }
+            hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, ac, make_geo<T, BK>(a), dbg);
+            return 0;
+        }
+    }
+    if (a.fold_x != nullptr) return fpd_fail(-2, "conv_tile: a folded BN-backward apply is compiled for TN <= 2 only (fpd_conv_fold_supported)");
     hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, ac, make_geo<T, BK>(a), dbg);
     return 0;
 }
@@ -365,11 +431,16 @@ int launch_tile(const fpd_conv_t& a, hipStream_t st) {
     return launch_tile_v<T, TN, BK, false>(a, st);
 }
 
+// 32-channel output tiles per block: 4 / 2 / 1 by K, halved while the launch would have fewer than 128 blocks
+static int tile_tn(int K, int mt) {
+    int tn = K > 64 ? 4 : (K > 32 ? 2 : 1);
+    while (tn > 1 && mt * cdiv(K, 32 * tn) < 128) tn >>= 1;       // small layers: more, shorter blocks
+    return tn;
+}
+
 template <typename T, int BK>
 int launch_tile_tn(const fpd_conv_t& a, hipStream_t st) {
-    const int mt = tiles_of(a);
-    int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
-    while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;     // small layers: more, shorter blocks
+    const int tn = tile_tn(a.K, tiles_of(a));
     if (tn == 4) return launch_tile<T, 4, BK>(a, st);
     if (tn == 2) return launch_tile<T, 2, BK>(a, st);
     return launch_tile<T, 1, BK>(a, st);
@@ -389,7 +460,8 @@ static bool halo_fits(const fpd_conv_t& a, int vpr) { return (tile_rows(a.W) + a
 template <typename T, int TN, int BK, bool ALLW>
 int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
-    const size_t lds = (size_t)(2 * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) +
+    const bool bwd = a.epi == FPD_EPI_BNRELU_BWD || b.epi == FPD_EPI_BNRELU_BWD;
+    const size_t lds = (size_t)((bwd ? 5 : 2) * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) +
                        std::max({tile_lds<T, TN, BK, ALLW>(a), tile_lds<T, TN, BK, ALLW>(b), epi});
     if (lds > LDS_MAX) return 1;
     static size_t configured = 0;
@@ -401,6 +473,20 @@ int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     }
     const int nbx_a = tiles_of(a), nbx_b = tiles_of(b);
     dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
+    if constexpr (TN <= 2) {
+        if (a.fold_x != nullptr || b.fold_x != nullptr) {
+            static size_t configured_f = 0;
+            if (lds > configured_f) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+                configured_f = lds;
+            }
+            hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a, 0);
+            return 0;
+        }
+    }
+    if (a.fold_x != nullptr || b.fold_x != nullptr) return fpd_fail(-2, "conv_tile pair: a folded BN-backward apply is compiled for TN <= 2 only");
     hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a, 0);
     return 0;
 }
@@ -418,15 +504,30 @@ int launch_pair(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
 
 template <typename T, int BK>
 int launch_pair_tn(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
-    const int mt = tiles_of(a) + tiles_of(b);
-    int tn = a.K > 64 ? 4 : (a.K > 32 ? 2 : 1);
-    while (tn > 1 && mt * cdiv(a.K, 32 * tn) < 128) tn >>= 1;
+    const int tn = tile_tn(a.K, tiles_of(a) + tiles_of(b));
     if (tn == 4) return launch_pair<T, 4, BK>(a, b, st);
     if (tn == 2) return launch_pair<T, 2, BK>(a, b, st);
     return launch_pair<T, 1, BK>(a, b, st);
 }
 
 }  // namespace
+
+// 1 if a BNRELU_BWD data gradient without a prologue BN is served by this kernel WITH a folded BN-backward apply
+// (fpd_conv_t.fold_x): the FOLD variants are compiled for TN <= 2 (register budget) and kept to channel counts for which
+// the LDS never runs out.
+static bool tile_fold_shape(const fpd_conv_t& a) {
+    if (a.epi != FPD_EPI_BNRELU_BWD || a.bn.mode != FPD_BN_NONE || !tile_domain(a) || a.C > 128 || a.K > 128) return false;
+    if (a.dtype == FPD_BF16) return halo_fits(a, ((a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16)) / 8);
+    return halo_fits(a, ((a.C % 32 == 0) ? 32 : 16) / 4);
+}
+int fpd_conv_tile_fold_ok(const fpd_conv_t& a) { return (tile_fold_shape(a) && tile_tn(a.K, tiles_of(a)) <= 2) ? 1 : 0; }
+// -1: this kernel would not pair the two (the caller launches them one by one); else 1 / 0 as above for the pair launch
+int fpd_conv_tile_pair_fold_ok(const fpd_conv_t& a, const fpd_conv_t& b) {
+    if (!tile_domain(a) || !tile_domain(b) || a.dtype != b.dtype || a.K != b.K || a.C != b.C || a.R != b.R) return -1;
+    const int vpr = a.dtype == FPD_BF16 ? ((a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16)) / 8 : ((a.C % 32 == 0) ? 32 : 16) / 4;
+    if (!halo_fits(a, vpr) || !halo_fits(b, vpr)) return -1;
+    return (tile_fold_shape(a) && tile_fold_shape(b) && tile_tn(a.K, tiles_of(a) + tiles_of(b)) <= 2) ? 1 : 0;
+}
 
 // Two independent convolutions in one launch; 1 = the pair is outside the domain (caller launches them one by one).
 // Requires both in the halo-tile domain with the same dtype, K (n-tiling), R and channel chunking.
