@@ -367,7 +367,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     // zero on the dy side)
     const int kstep = a.dtype == FPD_BF16 ? 16 : 2;
     const bool row_aligned = a.W % kstep == 0;
-    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < (row_aligned ? 16 : 12)) return false;
+    if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < (row_aligned ? 16 : 4)) return false;
     if (!row_aligned && !(a.dtype == FPD_BF16 && a.W % 4 == 0)) return false;
     g.h4 = !row_aligned && a.R == 3;
     if (a.C % 16 != 0 || a.K % 16 != 0) return false;
