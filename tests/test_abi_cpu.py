@@ -106,3 +106,56 @@ def test_round2_entry_points_validate_their_arguments_without_a_device(runtime):
     assert lib.fpd_plan_add(p, R.OP_CONV_F8, R.C.byref(c8), R.C.sizeof(c8)) == 0
     assert lib.fpd_plan_add(p, R.OP_CONV_F8, R.C.byref(c), R.C.sizeof(c)) < 0        # wrong args size for the op
     lib.fpd_plan_destroy(p)
+
+
+def _conv(R, N, H, W, C, K, r, bwd=True, bn=False, dtype=None):
+    a = R.ConvT()
+    a.x = a.w = a.y = 64                          # never dereferenced by the predicates below
+    a.N, a.H, a.W, a.C, a.K, a.R, a.S, a.stride, a.pad, a.P, a.Q = N, H, W, C, K, r, r, 1, (r - 1) // 2, H, W
+    a.dtype = R.BF16 if dtype is None else dtype
+    a.epi = R.EPI_BNRELU_BWD if bwd else R.EPI_PLAIN
+    if bwd:
+        a.epi_x, a.epi_stats = 64, 64
+        a.epi_bn.mode, a.epi_bn.gamma, a.epi_bn.beta, a.epi_bn.stats = R.BN_TRAIN, 64, 64, 64
+    if bn:
+        a.bn.mode, a.bn.gamma, a.bn.beta, a.bn.stats = R.BN_TRAIN, 64, 64, 64
+    return a
+
+
+def test_host_side_dispatch_predicates_of_round_3_without_a_device(runtime):
+    """Pure host logic of the round-3 entry points: which launches evaluate a folded BN-backward apply (persistent kernel
+    from 256 pixel tiles, the halo-tile kernel's FOLD variants below that only while its blocks carry <= 64 output
+    channels), how many slabs the deterministic weight-gradient kernels write, and the options of fpd_set_option."""
+    import ctypes
+    R, lib = runtime, runtime.lib()
+    if not all(hasattr(R, n) for n in ('BF16', 'EPI_BNRELU_BWD', 'EPI_PLAIN', 'BN_TRAIN')):
+        pytest.skip('runtime.py does not export the enum names this test uses')
+    fold = lambda a: lib.fpd_conv_fold_supported(ctypes.byref(a))
+    # data gradients of the student's Bottlenecks at batch 32: 64x64 and 32x32 -> persistent kernel, 16x16 and below -> halo tile
+    assert fold(_conv(R, 32, 64, 64, 64, 128, 1)) == 1          # dgrad of conv1 (1x1, 128 <- 64)
+    assert fold(_conv(R, 32, 64, 64, 64, 64, 3)) == 1           # dgrad of conv2 (3x3)
+    assert fold(_conv(R, 32, 32, 32, 64, 128, 1)) == 1
+    assert fold(_conv(R, 32, 16, 16, 64, 128, 1)) == 1          # 64 tiles: halo-tile kernel, TN drops to 2
+    assert fold(_conv(R, 32, 4, 4, 64, 64, 3)) == 1
+    # 128 tiles x 128 output channels: the halo-tile kernel keeps TN = 4, for which no FOLD variant is compiled
+    assert fold(_conv(R, 4, 64, 64, 64, 128, 1)) == 0
+    assert fold(_conv(R, 32, 64, 64, 64, 64, 3, bwd=False)) == 0        # not a BNRELU_BWD data gradient
+    assert fold(_conv(R, 32, 64, 64, 64, 64, 3, bn=True)) == 0          # a prologue BN of its own
+    pair = R.ConvPairT()
+    pair.a, pair.b = _conv(R, 32, 64, 64, 64, 128, 1), _conv(R, 32, 32, 32, 64, 128, 1)
+    assert lib.fpd_conv_pair_fold_supported(ctypes.byref(pair)) == 1
+    pair.a, pair.b = _conv(R, 4, 64, 64, 64, 128, 1), _conv(R, 4, 32, 32, 64, 128, 1)      # 160 tiles: halo-tile pair at TN = 4
+    assert lib.fpd_conv_pair_fold_supported(ctypes.byref(pair)) == 0
+    # deterministic weight gradients: slab counts follow the dispatch order tile -> mfma -> small-C -> direct
+    w = R.WgradT()
+    w.x = w.dy = w.dw = 64
+    w.N, w.H, w.W, w.C, w.K, w.R, w.S, w.stride, w.pad, w.P, w.Q = 32, 64, 64, 64, 64, 3, 3, 1, 1, 64, 64
+    w.dtype = R.BF16
+    assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) == 128                       # 3x3 halo-tile kernel: one slab per block
+    w.H = w.W = w.P = w.Q = 24                                                     # HRNet width: H4 variant of the same kernel
+    assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) > 0
+    w.N, w.H, w.W, w.P, w.Q, w.C, w.K, w.stride = 32, 256, 192, 128, 96, 3, 64, 2   # HRNet stem: the small-C kernel
+    assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) == 512
+    assert lib.fpd_set_option(b'no_such_option', 1) < 0 and b'unknown' in lib.fpd_last_error()
+    prev = lib.fpd_set_option(b'conv_pp_blocks', 64)
+    assert prev == 256 and lib.fpd_set_option(b'conv_pp_blocks', prev) == 64
