@@ -65,6 +65,23 @@ int fpd_nhwc_to_nchw_launch(const void* src, float* dst, int N, int C, int H, in
 int g_fpd_backend = FPD_BACKEND_MFMA;
 static thread_local char g_err[512] = "";
 
+// ---- launch log (common.h FPD_LAUNCH) ----
+static FILE* g_launch_log_file = nullptr;
+static bool launch_log_open() {
+    const char* path = getenv("FPD_LAUNCH_LOG");
+    if (path == nullptr || path[0] == 0) return false;
+    g_launch_log_file = fopen(path, "w");
+    if (g_launch_log_file == nullptr) fprintf(stderr, "[fpd_amd] FPD_LAUNCH_LOG: cannot open %s\n", path);
+    return g_launch_log_file != nullptr;
+}
+bool g_fpd_launch_log = launch_log_open();
+static thread_local char g_op_tag[256] = "-";          // the plan op being issued (set by fpd_plan_run / fpd_plan_run_op)
+void fpd_log_launch(const char* kernel, const dim3& grid, const dim3& block) {
+    if (g_launch_log_file == nullptr) return;
+    fprintf(g_launch_log_file, "%s\t%u\t%u\t%s\n", kernel, grid.x * grid.y * grid.z, block.x * block.y * block.z, g_op_tag);
+    fflush(g_launch_log_file);
+}
+
 int fpd_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -559,6 +576,43 @@ int fpd_plan_wait_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
     return 0;
 }
 
+static void conv_tag(char* p, size_t n, const char* what, const fpd_conv_t& c) {
+    snprintf(p, n, "%s N=%d H=%d W=%d C=%d K=%d R=%d s=%d %s%s%s%s", what, c.N, c.H, c.W, c.C, c.K, c.R, c.stride,
+             c.epi == FPD_EPI_BNRELU_BWD ? "dgrad" : "fwd", c.bn.mode == FPD_BN_EVAL ? " evalbn" : "", c.wg_partial ? " +wgrad" : "", c.fold_x ? " +fold" : "");
+}
+// "<plan op index> <what> <shape>": the key tools/profile_summarize.py groups trace rows by
+static void set_op_tag(int idx, const fpd_op& o) {
+    char t[200] = "";
+    static const char* ew_names[] = {"bnrelu_fwd", "bnrelu_bwd_r", "bn_bwd_apply", "maxpool_fwd", "maxpool_bwd", "upadd_fwd", "sumpool", "add", "relu_mask", "dilate2"};
+    auto ewn = [&](int op) { return (op >= 0 && op < 10) ? ew_names[op] : "ew"; };
+    switch (o.type) {
+        case FPD_OP_CONV: conv_tag(t, sizeof(t), "conv", o.u.conv); break;
+        case FPD_OP_CONV_F8: conv_tag(t, sizeof(t), "conv_f8", o.u.conv8.c); break;
+        case FPD_OP_CONV_PAIR: {
+            char a[90], b[90];
+            conv_tag(a, sizeof(a), "conv2", o.u.pair.a);
+            snprintf(b, sizeof(b), " | H=%d W=%d", o.u.pair.b.H, o.u.pair.b.W);
+            snprintf(t, sizeof(t), "%s%s", a, b);
+            break;
+        }
+        case FPD_OP_WGRAD: snprintf(t, sizeof(t), "wgrad N=%d H=%d W=%d C=%d K=%d R=%d s=%d", o.u.wgrad.N, o.u.wgrad.H, o.u.wgrad.W, o.u.wgrad.C, o.u.wgrad.K, o.u.wgrad.R, o.u.wgrad.stride); break;
+        case FPD_OP_BNECK: snprintf(t, sizeof(t), "bneck N=%d H=%d W=%d C=%d P=%d", o.u.bneck.N, o.u.bneck.H, o.u.bneck.W, o.u.bneck.C, o.u.bneck.P); break;
+        case FPD_OP_BNECK_PAIR: snprintf(t, sizeof(t), "bneck2 N=%d H=%d W=%d C=%d P=%d | H=%d W=%d", o.u.bpair.a.N, o.u.bpair.a.H, o.u.bpair.a.W, o.u.bpair.a.C, o.u.bpair.a.P, o.u.bpair.b.H, o.u.bpair.b.W); break;
+        case FPD_OP_HEAD: snprintf(t, sizeof(t), "head N=%d H=%d W=%d C=%d J=%d", o.u.head.N, o.u.head.H, o.u.head.W, o.u.head.C, o.u.head.J); break;
+        case FPD_OP_EW: snprintf(t, sizeof(t), "ew %s N=%d H=%d W=%d C=%d", ewn(o.u.ew.op), o.u.ew.N, o.u.ew.H, o.u.ew.W, o.u.ew.C); break;
+        case FPD_OP_EW_PAIR: snprintf(t, sizeof(t), "ew2 %s N=%d H=%d W=%d C=%d | H=%d W=%d", ewn(o.u.epair.a.op), o.u.epair.a.N, o.u.epair.a.H, o.u.epair.a.W, o.u.epair.a.C, o.u.epair.b.H, o.u.epair.b.W); break;
+        case FPD_OP_STEM_FWD: case FPD_OP_STEM_WGRAD: snprintf(t, sizeof(t), "%s N=%d H=%d W=%d K=%d", o.type == FPD_OP_STEM_FWD ? "stem_fwd" : "stem_wgrad", o.u.stem.N, o.u.stem.H, o.u.stem.W, o.u.stem.K); break;
+        case FPD_OP_AFFSUM: snprintf(t, sizeof(t), "affsum N=%d H=%d W=%d C=%d terms=%d", o.u.affsum.N, o.u.affsum.H, o.u.affsum.W, o.u.affsum.C, o.u.affsum.nterms); break;
+        case FPD_OP_LOSS: snprintf(t, sizeof(t), "loss B=%d J=%d H=%d W=%d S=%d", o.u.loss.B, o.u.loss.J, o.u.loss.H, o.u.loss.W, o.u.loss.S); break;
+        case FPD_OP_ADAM: snprintf(t, sizeof(t), "adam n=%lld", (long long)o.u.adam.n); break;
+        case FPD_OP_WREDUCE: snprintf(t, sizeof(t), "wreduce entries=%d", o.u.table.n); break;
+        case FPD_OP_WPREP: snprintf(t, sizeof(t), "wprep entries=%d", o.u.table.n); break;
+        case FPD_OP_BNUPD: snprintf(t, sizeof(t), "bnupd entries=%d", o.u.table.n); break;
+        default: snprintf(t, sizeof(t), "op%d", o.type); break;
+    }
+    snprintf(g_op_tag, sizeof(g_op_tag), "%d\t%s", idx, t);
+}
+
 static int run_op(const fpd_op& o, fpd_stream_t s) {
     switch (o.type) {
         case FPD_OP_CONV: return fpd_conv_forward(&o.u.conv, s);
@@ -643,6 +697,7 @@ int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
         }
         for (int32_t w : sc.waits)
             if (w >= begin && w < end) FPD_CHECK_HIP(hipStreamWaitEvent(st, p->sched[w].done, 0));
+        if (g_fpd_launch_log) set_op_tag(i, p->ops[i]);
         rc = run_op(p->ops[i], (fpd_stream_t)st);
         if (rc) {
             char tmp[400];
@@ -666,6 +721,7 @@ int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
 
 int fpd_plan_run_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
     FPD_REQUIRE(p && op >= 0 && op < (int)p->ops.size(), "plan_run_op: bad op index %d", op);
+    if (g_fpd_launch_log) set_op_tag(op, p->ops[op]);
     return run_op(p->ops[op], stream);
 }
 

@@ -603,13 +603,8 @@ size_t bneck_lds_bytes(int H, int W) {
 template <int P, bool DMA>
 int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st) {
     const size_t lds = std::max(bneck_lds_bytes<P>(a.H, a.W), bneck_lds_bytes<P>(b.H, b.W));
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P, DMA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&bneck_eval_pair_kernel<P, DMA>), lds)) return rc_;
     int la = 0, lb = 0;
     while ((1 << la) < a.W) ++la;
     while ((1 << lb) < b.W) ++lb;
@@ -621,22 +616,17 @@ int launch_bneck_pair(const fpd_bneck_t& a, const fpd_bneck_t& b, hipStream_t st
         nb = bneck_blocks(tb, capb);
         na = bneck_blocks(ta, std::max(1, cap - nb));
     }
-    hipLaunchKernelGGL((bneck_eval_pair_kernel<P, DMA>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, ta, tb);
+    FPD_LAUNCH((bneck_eval_pair_kernel<P, DMA>), dim3(na + nb), dim3(512), lds, st, a, b, la, lb, na, ta, tb);
     return 0;
 }
 
 template <int P, bool DMA>
 int launch_bneck(const fpd_bneck_t& a, int logW, hipStream_t st) {
     const size_t lds = bneck_lds_bytes<P>(a.H, a.W);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck_eval_kernel<P, DMA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&bneck_eval_kernel<P, DMA>), lds)) return rc_;
     const int ntiles = cdiv(a.N * a.H * a.W, 128);
-    hipLaunchKernelGGL((bneck_eval_kernel<P, DMA>), dim3(bneck_blocks(ntiles, bneck_block_cap())), dim3(512), lds, st, a, logW, ntiles);
+    FPD_LAUNCH((bneck_eval_kernel<P, DMA>), dim3(bneck_blocks(ntiles, bneck_block_cap())), dim3(512), lds, st, a, logW, ntiles);
     return 0;
 }
 
@@ -668,7 +658,7 @@ int fpd_bneck_fused_pair_launch(const fpd_bneck_t& a, const fpd_bneck_t& b, hipS
 // folded tables ([3C + 4P] floats) for a.folded; 1 = P not supported
 int fpd_bneck_fold_launch(const fpd_bneck_t& a, float* out, hipStream_t st) {
     if (a.C != 2 * a.P || (a.P != 64 && a.P != 128)) return 1;
-    if (a.P == 128) hipLaunchKernelGGL((bneck_fold_kernel<128>), dim3(1), dim3(256), 0, st, a, out);
-    else hipLaunchKernelGGL((bneck_fold_kernel<64>), dim3(1), dim3(256), 0, st, a, out);
+    if (a.P == 128) FPD_LAUNCH((bneck_fold_kernel<128>), dim3(1), dim3(256), 0, st, a, out);
+    else FPD_LAUNCH((bneck_fold_kernel<64>), dim3(1), dim3(256), 0, st, a, out);
     return 0;
 }

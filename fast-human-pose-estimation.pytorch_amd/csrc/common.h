@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "fpd_amd.h"
 
 #define FPD_MAXC 512  // largest channel count a fused BN prologue supports (HRNet-W48 peak is 384)
@@ -27,6 +30,39 @@ int fpd_fail(int code, const char* fmt, ...);  // sets fpd_last_error(), returns
     } while (0)
 
 extern int g_fpd_backend;
+
+// Every kernel launch of the library goes through FPD_LAUNCH.  With FPD_LAUNCH_LOG=<file> in the environment each launch is
+// also appended to that file in host order -- "<kernel expression>\t<grid>\t<block>\t<plan op tag: index, type, shape>" -- so
+// that the rows of a rocprofv3 kernel trace (same host order: Dispatch_Id) can be keyed on the tensor shape a launch worked
+// on, which the trace itself does not carry (tools/profile_summarize.py).  Off (the default): one predictable branch.
+extern bool g_fpd_launch_log;
+void fpd_log_launch(const char* kernel, const dim3& grid, const dim3& block);
+#define FPD_LAUNCH(kernel, grid, block, lds, stream, ...)                     \
+    do {                                                                       \
+        if (g_fpd_launch_log) fpd_log_launch(#kernel, grid, block);            \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);     \
+    } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel: a per-DEVICE attribute, raised at most once per size and
+// device; concurrent callers (one host thread per device) are serialised on the slow path only.
+constexpr int FPD_MAX_DEVICES = 64;
+struct LdsAttr {
+    std::atomic<size_t> done[FPD_MAX_DEVICES];      // static storage: zero-initialised
+    std::mutex mu;
+    int ensure(const void* fn, size_t lds) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipGetDevice: %s", hipGetErrorString(e));
+        if (dev < 0 || dev >= FPD_MAX_DEVICES) return fpd_fail(-2, "device ordinal %d outside [0,%d)", dev, FPD_MAX_DEVICES);
+        if (lds <= done[dev].load(std::memory_order_acquire)) return 0;
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds <= done[dev].load(std::memory_order_relaxed)) return 0;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        done[dev].store(lds, std::memory_order_release);
+        return 0;
+    }
+};
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 // two floats -> packed bf16x2 (lo = a), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
@@ -71,46 +107,85 @@ struct DT<bf16_t> {
     }
 };
 
-// ---- BatchNorm coefficients from batch statistics (TRAIN) or running estimates (EVAL) --------
-// a = x*scale + shift  ==  gamma*(x-mean)*invstd + beta.  Mean/variance are derived in fp64
-// from fp64 sums (biased variance, like torch's batch_norm); scale/shift are rounded once.
-__device__ __forceinline__ void bn_coef(const fpd_bn_t& bn, int c, int C, double count, float& scale,
-                                        float& shift, float& mean, float& invstd) {
-    double m, var;
-    if (bn.mode == FPD_BN_TRAIN) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
-        for (int r = 0; r < FPD_STATS_REPLICAS; ++r) { s1 += bn.stats[r * 2 * C + c]; s2 += bn.stats[r * 2 * C + C + c]; }
-        m = s1 / count;
-        var = s2 / count - m * m;
-        if (var < 0.0) var = 0.0;
-    } else {
-        m = (double)bn.running_mean[c];
-        var = (double)bn.running_var[c];
+// ---- exact statistics (include/fpd_amd.h, fpd_stat_t): a value travels as two 64-bit integer limbs ----------------
+// Integer addition is associative, so the sums do not depend on the order in which blocks (device atomics) or threads
+// (LDS atomics) contribute: bit-repeatable statistics at the cost of an fp64 atomic pair (tools/probes/pdl_probe.hip).
+#define FPD_STAT_HI_SCALE 256.0                       // hi limb: units of 2^-8
+#define FPD_STAT_LO_SCALE 1152921504606846976.0       // lo limb: units of 2^-60
+struct StatLimbs { long long hi, lo; };
+__device__ __forceinline__ StatLimbs stat_split(double v) {
+    const double lim = 18014398509481984.0;           // 2^54: beyond it (or NaN) the network has diverged; stay finite and huge
+    v = (v == v) ? fmin(fmax(v, -lim), lim) : lim;
+    StatLimbs s;
+    s.hi = __double2ll_rn(v * FPD_STAT_HI_SCALE);
+    s.lo = __double2ll_rn((v - (double)s.hi * (1.0 / FPD_STAT_HI_SCALE)) * FPD_STAT_LO_SCALE);
+    return s;
+}
+__device__ __forceinline__ double stat_join(long long hi, long long lo) {
+    return (double)hi * (1.0 / FPD_STAT_HI_SCALE) + (double)lo * (1.0 / FPD_STAT_LO_SCALE);
+}
+// replica of a statistics buffer this block adds into
+__device__ __forceinline__ int stats_replica() { return (int)((blockIdx.x + blockIdx.y * gridDim.x) % FPD_STATS_REPLICAS); }
+// sum `s` (0 / 1) of channel c += v, into the calling block's replica of a buffer over C channels
+__device__ __forceinline__ void stat_atomic_add(fpd_stat_t* buf, int C, int s, int c, double v) {
+    const StatLimbs l = stat_split(v);
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf) + ((size_t)stats_replica() * 4 + 2 * s) * C + c;
+    atomicAdd(p, (unsigned long long)l.hi);
+    atomicAdd(p + C, (unsigned long long)l.lo);
+}
+// the same into an LDS accumulator [2 sums][2 limbs][C] (threads of a block in any order)
+__device__ __forceinline__ void stat_lds_add(long long* acc, int C, int s, int c, double v) {
+    const StatLimbs l = stat_split(v);
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(acc) + (size_t)(2 * s) * C + c;
+    atomicAdd(p, (unsigned long long)l.hi);
+    atomicAdd(p + C, (unsigned long long)l.lo);
+}
+// LDS accumulator -> the block's replica (limbs are added as they are: still exact)
+__device__ __forceinline__ void stat_flush_lds(fpd_stat_t* buf, const long long* acc, int C, int c) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf) + (size_t)stats_replica() * 4 * C + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(p + q * C, (unsigned long long)acc[q * C + c]);
+}
+// raw limbs of sum s of channel c, all replicas: two halves so that the loads can be issued long before they are needed
+struct StatRaw { long long hi[FPD_STATS_REPLICAS], lo[FPD_STATS_REPLICAS]; };
+__device__ __forceinline__ void stat_request(const fpd_stat_t* buf, int C, int s, int c, StatRaw& r) {
+#pragma unroll
+    for (int q = 0; q < FPD_STATS_REPLICAS; ++q) {
+        r.hi[q] = buf[((size_t)q * 4 + 2 * s) * C + c];
+        r.lo[q] = buf[((size_t)q * 4 + 2 * s + 1) * C + c];
     }
-    const double is = 1.0 / sqrt(var + (double)bn.eps);
-    const double g = (double)bn.gamma[c];
-    mean = (float)m;
-    invstd = (float)is;
-    scale = (float)(g * is);
-    shift = (float)((double)bn.beta[c] - m * g * is);
+}
+__device__ __forceinline__ double stat_resolve(const StatRaw& r) {
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { hi += r.hi[q]; lo += r.lo[q]; }
+    return stat_join(hi, lo);
+}
+// sum over replicas of sum s of channel c
+__device__ __forceinline__ double stats_sum(const fpd_stat_t* buf, int C, int s, int c) {
+    StatRaw r;
+    stat_request(buf, C, s, c, r);
+    return stat_resolve(r);
 }
 
+// ---- BatchNorm coefficients from batch statistics (TRAIN) or running estimates (EVAL) --------
+// a = x*scale + shift  ==  gamma*(x-mean)*invstd + beta.  Mean/variance are derived in fp64
+// from the exact sums (biased variance, like torch's batch_norm); scale/shift are rounded once.
 // The same coefficients in two halves, for prologues that want every load in flight before any of the fp64 arithmetic:
-// bn_request() only issues the loads of channel c, bn_resolve() does the arithmetic of bn_coef() on what arrived.
-struct BnRaw { double s[2 * FPD_STATS_REPLICAS]; float g, b, eps; int mode; };
+// bn_request() only issues the loads of channel c, bn_resolve() does the arithmetic on what arrived.
+struct BnRaw { StatRaw s1, s2; float g, b, eps, rm, rv; int mode; };
 __device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnRaw& r) {
     r.mode = bn.mode; r.eps = bn.eps;
 #pragma unroll
-    for (int q = 0; q < 2 * FPD_STATS_REPLICAS; ++q) r.s[q] = 0.0;
-    r.g = 1.f; r.b = 0.f;
+    for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { r.s1.hi[q] = r.s1.lo[q] = r.s2.hi[q] = r.s2.lo[q] = 0; }
+    r.g = 1.f; r.b = 0.f; r.rm = 0.f; r.rv = 1.f;
     if (bn.mode == FPD_BN_NONE) return;
     if (bn.mode == FPD_BN_TRAIN) {
-#pragma unroll
-        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { r.s[2 * q] = bn.stats[q * 2 * C + c]; r.s[2 * q + 1] = bn.stats[q * 2 * C + C + c]; }
+        stat_request(bn.stats, C, 0, c, r.s1);
+        stat_request(bn.stats, C, 1, c, r.s2);
     } else {
-        r.s[0] = (double)bn.running_mean[c];
-        r.s[1] = (double)bn.running_var[c];
+        r.rm = bn.running_mean[c];
+        r.rv = bn.running_var[c];
     }
     r.g = bn.gamma[c];
     r.b = bn.beta[c];
@@ -118,15 +193,12 @@ __device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnR
 __device__ __forceinline__ void bn_resolve(const BnRaw& r, double count, float& scale, float& shift, float& mean, float& invstd) {
     double m, var;
     if (r.mode == FPD_BN_TRAIN) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += r.s[2 * q]; s2 += r.s[2 * q + 1]; }   // same order as bn_coef()
-        m = s1 / count;
-        var = s2 / count - m * m;
+        m = stat_resolve(r.s1) / count;
+        var = stat_resolve(r.s2) / count - m * m;
         if (var < 0.0) var = 0.0;
     } else {
-        m = r.s[0];
-        var = r.s[1];
+        m = (double)r.rm;
+        var = (double)r.rv;
     }
     const double is = 1.0 / sqrt(var + (double)r.eps);
     const double g = (double)r.g;
@@ -134,6 +206,12 @@ __device__ __forceinline__ void bn_resolve(const BnRaw& r, double count, float& 
     invstd = (float)is;
     scale = (float)(g * is);
     shift = (float)((double)r.b - m * g * is);
+}
+__device__ __forceinline__ void bn_coef(const fpd_bn_t& bn, int c, int C, double count, float& scale,
+                                        float& shift, float& mean, float& invstd) {
+    BnRaw r;
+    bn_request(bn, c, C, r);
+    bn_resolve(r, count, scale, shift, mean, invstd);
 }
 
 // Fill LDS scale/shift tables for all C channels (call from every thread, then __syncthreads()).
@@ -162,16 +240,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-// replica of a [R][2][C] statistics buffer this block adds into
-__device__ __forceinline__ int stats_replica() { return (int)((blockIdx.x + blockIdx.y * gridDim.x) % FPD_STATS_REPLICAS); }
-// sum over replicas of element i of a [R][2][C] buffer
-__device__ __forceinline__ double stats_sum(const double* st, int C, int i) {
-    double s = 0.0;
-#pragma unroll 4
-    for (int r = 0; r < FPD_STATS_REPLICAS; ++r) s += st[r * 2 * C + i];
-    return s;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -3,7 +3,8 @@
 //   y = acc + bias (+ residual); then either
 //     - batch statistics of y for the next train-mode BN            (out_stats)
 //     - ReLU mask of epi_x + the two BatchNorm-backward sums        (FPD_EPI_BNRELU_BWD)
-// Statistics are accumulated in fp64 from the first add: var = E[x^2]-E[x]^2 must survive |mean| >> std.
+// Statistics are accumulated in fp64 from the first add: var = E[x^2]-E[x]^2 must survive |mean| >> std; every sum inside
+// the block is formed in a fixed order and the block's contribution leaves as exact integer limbs (common.h).
 #pragma once
 #include "common.h"
 
@@ -63,15 +64,15 @@ __device__ __forceinline__ void conv_epilogue(const fpd_conv_t& a, const f32x16*
             if (lane < 32) { s_red[(wave * BNT + tn * 32 + lane) * 2 + 0] = t1; s_red[(wave * BNT + tn * 32 + lane) * 2 + 1] = t2; }
         }
         __syncthreads();
-        double* st = (bwd ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
+        fpd_stat_t* st = bwd ? a.epi_stats : a.out_stats;
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
             if (k < K) {
                 double u1 = 0.0, u2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { u1 += s_red[(w * BNT + t) * 2]; u2 += s_red[(w * BNT + t) * 2 + 1]; }
-                atomicAdd(st + k, u1);
-                atomicAdd(st + K + k, u2);
+                stat_atomic_add(st, K, 0, k, u1);
+                stat_atomic_add(st, K, 1, k, u2);
             }
         }
     }
@@ -112,7 +113,6 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     const T* ex = reinterpret_cast<const T*>(a.epi_x);
     const bool bwd = a.epi == FPD_EPI_BNRELU_BWD;
     const bool want_stats = (a.out_stats != nullptr) || bwd;
-    const int edbg = a._pad;                               // FPD_EPI_DBG ablation bits (timing experiments only; 0 in production)
     float bias[VEC], esc[VEC], esh[VEC], emu[VEC], eis[VEC];
     float f1[VEC], f2[VEC], cshift[VEC];
     int nrow = 0;
@@ -213,12 +213,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                         }
                         ++nrow;
                     }
-                    if (!(edbg & 4)) *reinterpret_cast<uint4*>(y + off) = packed;
+                    *reinterpret_cast<uint4*>(y + off) = packed;
                 }
             }
         }
     }
-    if (want_stats && !(edbg & 1)) {
+    if (want_stats) {
         double s1[VEC], s2[VEC];
         if constexpr (sizeof(T) == 2) {
             // bf16 build: the lanes of a wave that own the same channel vector are combined in fp32 first (shuffles of
@@ -280,17 +280,15 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             }
         }
         __syncthreads();
-        double* st = (bwd ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
+        fpd_stat_t* st = bwd ? a.epi_stats : a.out_stats;
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
             if (k < K) {
                 double u1 = 0.0, u2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { u1 += s_red[(w * BNT + t) * 2]; u2 += s_red[(w * BNT + t) * 2 + 1]; }
-                if (!(edbg & 2)) {
-                    atomicAdd(st + k, u1);
-                    atomicAdd(st + K + k, u2);
-                }
+                stat_atomic_add(st, K, 0, k, u1);
+                stat_atomic_add(st, K, 1, k, u2);
             }
         }
     }

@@ -395,7 +395,7 @@ template <typename T, int TN, int BK>
 int launch_conv_t(const fpd_conv_t& a, hipStream_t st) {
     const int M = a.N * a.P * a.Q;
     dim3 grid(cdiv(M, 128), cdiv(a.K, 32 * TN));
-    hipLaunchKernelGGL((conv_mfma_kernel<T, TN, BK>), grid, dim3(256), 0, st, a);
+    FPD_LAUNCH((conv_mfma_kernel<T, TN, BK>), grid, dim3(256), 0, st, a);
     return 0;
 }
 
@@ -449,8 +449,8 @@ int fpd_wgrad_mfma_launch(const fpd_wgrad_t& a, hipStream_t st) {
     }
     dim3 grid(chunks, taps, ktiles * ctiles);
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a, pch, ctiles);
+        FPD_LAUNCH((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a, pch, ctiles);
     else
-        hipLaunchKernelGGL((wgrad_mfma_kernel<float>), grid, dim3(256), 0, st, a, pch, ctiles);
+        FPD_LAUNCH((wgrad_mfma_kernel<float>), grid, dim3(256), 0, st, a, pch, ctiles);
     return 0;
 }

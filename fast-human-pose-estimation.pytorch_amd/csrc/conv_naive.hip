@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
     // per block) -- per-element atomics otherwise (tiny / odd K only)
     const bool want_stats = a.epi == FPD_EPI_BNRELU_BWD || a.out_stats != nullptr;
     const bool fast = want_stats && ((size_t)gridDim.x * blockDim.x) % (size_t)K == 0 && K <= FPD_MAXC;
-    __shared__ double s_acc[2][FPD_MAXC];
+    __shared__ long long s_acc[4 * FPD_MAXC];          // [2 sums][2 limbs][K] exact accumulator (common.h)
     if (fast) {
-        for (int k = threadIdx.x; k < K; k += blockDim.x) { s_acc[0][k] = 0.0; s_acc[1][k] = 0.0; }
+        for (int k = threadIdx.x; k < 4 * K; k += blockDim.x) s_acc[k] = 0;
         __syncthreads();
     }
     double t1 = 0.0, t2 = 0.0;
@@ -66,29 +66,26 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const fpd_conv_t a) {
             const double u2 = (double)(vr * ((xv - s_epi[2][k]) * s_epi[3][k]));
             if (fast) { t1 += (double)vr; t2 += u2; }
             else {
-                atomicAdd(a.epi_stats + stats_replica() * 2 * K + k, (double)vr);
-                atomicAdd(a.epi_stats + stats_replica() * 2 * K + K + k, u2);
+                stat_atomic_add(a.epi_stats, K, 0, k, (double)vr);
+                stat_atomic_add(a.epi_stats, K, 1, k, u2);
             }
         } else if (a.out_stats) {
             const float vr = DT<T>::rnd(v);
             if (fast) { t1 += (double)vr; t2 += (double)vr * (double)vr; }
             else {
-                atomicAdd(a.out_stats + stats_replica() * 2 * K + k, (double)vr);
-                atomicAdd(a.out_stats + stats_replica() * 2 * K + K + k, (double)(vr * vr));
+                stat_atomic_add(a.out_stats, K, 0, k, (double)vr);
+                stat_atomic_add(a.out_stats, K, 1, k, (double)(vr * vr));
             }
         }
         DT<T>::st(y + idx, v);
     }
     if (fast) {
         const int k = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) % (size_t)K);
-        atomicAdd(&s_acc[0][k], t1);
-        atomicAdd(&s_acc[1][k], t2);
+        stat_lds_add(s_acc, K, 0, k, t1);
+        stat_lds_add(s_acc, K, 1, k, t2);
         __syncthreads();
-        double* dst = (a.epi == FPD_EPI_BNRELU_BWD ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
-        for (int c = threadIdx.x; c < K; c += blockDim.x) {
-            atomicAdd(dst + c, s_acc[0][c]);
-            atomicAdd(dst + K + c, s_acc[1][c]);
-        }
+        fpd_stat_t* dst = a.epi == FPD_EPI_BNRELU_BWD ? a.epi_stats : a.out_stats;
+        for (int c = threadIdx.x; c < K; c += blockDim.x) stat_flush_lds(dst, s_acc, K, c);
     }
 }
 
@@ -142,9 +139,9 @@ int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st) {
     const bool stats = a.out_stats != nullptr || a.epi == FPD_EPI_BNRELU_BWD;
     const int grid = (int)std::min<size_t>((total + 255) / 256, stats ? 2048 : 65536);    // statistics: few, long-lived blocks
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((conv_naive_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+        FPD_LAUNCH((conv_naive_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_naive_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+        FPD_LAUNCH((conv_naive_kernel<float>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -159,8 +156,8 @@ int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st) {
     const int total = a.K * a.R * a.S * a.C;
     const int chunks = a.partial != nullptr ? wgrad_naive_chunks(a) : 1;
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
+        FPD_LAUNCH((wgrad_naive_kernel<bf16_t>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
+        FPD_LAUNCH((wgrad_naive_kernel<float>), dim3(cdiv(total, 256), chunks), dim3(256), 0, st, a);
     return 0;
 }

@@ -242,12 +242,12 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const bool r_epi = a.epi == FPD_EPI_BNRELU_BWD && te >= 0 && te < KP;
     const bool r_bias = tb >= 0 && tb < KP;
     const bool r_fold = fold && tid < C;
-    double fs1[FPD_STATS_REPLICAS], fs2[FPD_STATS_REPLICAS];
+    StatRaw fs1, fs2;
     if (r_bn) bn_request(a.bn, tid, C, braw);
     else if (r_fold) {
         bn_request(a.fold_bn, tid, C, braw);
-#pragma unroll
-        for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { fs1[q] = a.fold_stats[q * 2 * C + tid]; fs2[q] = a.fold_stats[q * 2 * C + C + tid]; }
+        stat_request(a.fold_stats, C, 0, tid, fs1);
+        stat_request(a.fold_stats, C, 1, tid, fs2);
     }
     else if (r_epi && n0 + te < K) bn_request(a.epi_bn, n0 + te, K, braw);
     else if (r_bias && a.bias != nullptr && n0 + tb < K) bias_raw = a.bias[n0 + tb];
@@ -272,9 +272,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             s_shift[tid] = sh;
         } else if (r_fold) {
             // dy = gamma*is*(g - m1 - xhat*m2), xhat = (u - mu)*is  ==  A g + B u + D   (coefficients formed in fp64)
-            double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += braw.s[2 * q]; s2 += braw.s[2 * q + 1]; b1 += fs1[q]; b2 += fs2[q]; }
+            const double s1 = stat_resolve(braw.s1), s2 = stat_resolve(braw.s2), b1 = stat_resolve(fs1), b2 = stat_resolve(fs2);
             const double cnt = (double)M, mu = s1 / cnt;
             double var = s2 / cnt - mu * mu;
             if (var < 0.0) var = 0.0;
@@ -572,7 +570,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     // backward: {sum dz, sum dz * xhat}, c = 0) of 8 channels over its rows.  The 16 lanes of a channel chunk are combined by
     // a transposition through the wave's own staging tile (48 LDS reads per lane; a shuffle tree is 77 dependent
     // ds_bpermute round trips, 3 us at the end of every block), un-shifted once in fp64, then the waves of a channel half
-    // are added in a fixed order and ONE fp64 atomic pair per channel leaves the block.
+    // are added in a fixed order and ONE exact pair of sums (integer limbs, common.h) per channel leaves the block.
     if (want_stats) {
         float* rec = reinterpret_cast<float*>(sS + wave * (32 * LDST));      // [64 lanes][17]: f1[8] f2[8] nrow
 #pragma unroll
@@ -607,7 +605,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             s_red[(wave * 32 + lane) * 2 + 1] = s2;
         }
         __syncthreads();
-        double* st = (BWD ? a.epi_stats : a.out_stats) + (size_t)stats_replica() * 2 * K;
+        fpd_stat_t* st = BWD ? a.epi_stats : a.out_stats;
         for (int t = tid; t < KP; t += 512) {
             if (n0 + t < K) {
                 const int h2 = t >> 5, c32 = t & 31;      // the PXW waves of channel half h2 hold partial sums of channel t
@@ -617,8 +615,8 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                     u1 += s_red[((h2 * PXW + q) * 32 + c32) * 2];
                     u2 += s_red[((h2 * PXW + q) * 32 + c32) * 2 + 1];
                 }
-                atomicAdd(st + n0 + t, u1);
-                atomicAdd(st + K + n0 + t, u2);
+                stat_atomic_add(st, K, 0, n0 + t, u1);
+                stat_atomic_add(st, K, 1, n0 + t, u2);
             }
         }
     }
@@ -766,16 +764,11 @@ static bool pp_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, PPPl
 
 template <int R, int C, int KH, bool BWD, bool WG>
 static int pp_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, const PPPlan& pl, hipStream_t st) {
-    static size_t configured = 0;
-    if (pl.lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, KH, BWD, WG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", pl.lds, hipGetErrorString(e));
-        configured = pl.lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_pp_kernel<R, C, KH, BWD, WG>), pl.lds)) return rc_;
     PPArgs args;
     args.c[0] = a; args.c[1] = b ? *b : a; args.g[0] = pl.ga; args.g[1] = pl.gb; args.ks = pl.ks;
-    hipLaunchKernelGGL((conv_pp_kernel<R, C, KH, BWD, WG>), dim3(pl.grid), dim3(512), pl.lds, st, args);
+    FPD_LAUNCH((conv_pp_kernel<R, C, KH, BWD, WG>), dim3(pl.grid), dim3(512), pl.lds, st, args);
     return 0;
 }
 
@@ -796,9 +789,17 @@ static int pp_launch(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
     if (want_wg) {
         if (!pl.wg) return fpd_fail(-2, "conv: a fused weight gradient was requested for a launch fpd_conv_fused_wgrad_partials() reports 0 for");
         const fpd_conv_t* cs[2] = {&a, b};
-        for (int i = 0; i < 2; ++i)
-            if (cs[i] != nullptr && cs[i]->wg_partial != nullptr && cs[i]->wg_stride < (int64_t)cs[i]->C * cs[i]->K + cs[i]->C)
+        const int nblk[2] = {pl.ga.nblk, pl.gb.nblk};
+        for (int i = 0; i < 2; ++i) {
+            if (cs[i] == nullptr || cs[i]->wg_partial == nullptr) continue;
+            if (cs[i]->wg_stride < (int64_t)cs[i]->C * cs[i]->K + cs[i]->C)
                 return fpd_fail(-2, "conv: wg_stride %lld smaller than weight + bias", (long long)cs[i]->wg_stride);
+            // the slab count was asked for when the workspace was sized; a geometry that has changed since (conv_pp_blocks) would
+            // write past the workspace or leave slabs unwritten
+            if (cs[i]->wg_count != nblk[i])
+                return fpd_fail(-2, "conv: the launch writes %d weight-gradient slabs but the caller sized its workspace for %d "
+                                    "(fpd_conv_fused_wgrad_partials: has a conv_pp option changed since?)", nblk[i], cs[i]->wg_count);
+        }
     }
     if (a.R == 3) {
         if (a.C == 64) return pp_launch_c<3, 64>(a, b, pl, st);
@@ -852,7 +853,13 @@ int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_
 int fpd_conv_pp_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b) {
     if (a.epi != FPD_EPI_BNRELU_BWD || a.bn.mode != FPD_BN_NONE) return 0;
     if (b != nullptr && (b->epi != FPD_EPI_BNRELU_BWD || b->bn.mode != FPD_BN_NONE)) return 0;
-    return pp_takes(a, b) ? 1 : 0;
+    if (!pp_takes(a, b)) return 0;
+    // exactly what pp_launch() will decide: the launch may still be declined by its geometry (LDS, a pair with < 2 ranges),
+    // with and without the fused weight gradient
+    PPPlan pl;
+    if (!pp_plan(a, b, false, pl)) return 0;
+    if (pp_wg_shape(a) && (b == nullptr || pp_wg_shape(*b)) && !pp_plan(a, b, true, pl)) return 0;
+    return 1;
 }
 
 int fpd_conv_pp_wgrad_partials(const fpd_conv_t& a) {

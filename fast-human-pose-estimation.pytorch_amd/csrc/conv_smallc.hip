@@ -17,7 +17,7 @@ template <typename T, int R, int C>
 __global__ __launch_bounds__(256) void conv_smallc_kernel(const fpd_conv_t a) {
     constexpr int NT = R * R * C, NTP = (NT + 3) & ~3, VEC = DT<T>::VEC;
     __shared__ __attribute__((aligned(16))) float s_w[64 * NTP];
-    __shared__ double s_acc[2][64];
+    __shared__ long long s_acc[4 * 64];            // [2 sums][2 limbs][64] exact accumulator (common.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int H = a.H, W = a.W, K = a.K, P = a.P, Q = a.Q;
     const int M = a.N * P * Q;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const fpd_conv_t a) {
             const int k = i / NTP, t = i - k * NTP;
             s_w[i] = (k < kn && t < NT) ? DT<T>::ld(w + (size_t)(k0 + k) * NT + t) : 0.f;
         }
-        if (tid < 64) { s_acc[0][tid] = 0.0; s_acc[1][tid] = 0.0; }
+        if (tid < 256) s_acc[tid] = 0;
         __syncthreads();
         // eight output channels at a time (one 16-byte vector of bf16): 8 accumulators, their weights as broadcast vectors
 #pragma unroll 1
@@ -128,17 +128,17 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const fpd_conv_t a) {
                 }
                 if ((lane & 7) == 0) {
                     const int ch = kb + ((lane >> 3) & 7);
-                    atomicAdd(&s_acc[0][ch], (double)s1[0]);
-                    atomicAdd(&s_acc[1][ch], (double)s2[0]);
+                    stat_lds_add(s_acc, 64, 0, ch, (double)s1[0]);
+                    stat_lds_add(s_acc, 64, 1, ch, (double)s2[0]);
                 }
             }
         }
         if (a.out_stats != nullptr) {
             __syncthreads();
             if (tid < kn) {
-                double* dst = a.out_stats + (size_t)stats_replica() * 2 * K;
-                atomicAdd(dst + k0 + tid, s_acc[0][tid]);
-                atomicAdd(dst + K + k0 + tid, s_acc[1][tid]);
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out_stats) + (size_t)stats_replica() * 4 * K + k0 + tid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(dst + q * K, (unsigned long long)s_acc[q * 64 + tid]);
             }
         }
     }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const fpd_conv_t a) {
 template <typename T, int R, int C>
 int launch_smallc(const fpd_conv_t& a, hipStream_t st) {
     const int M = a.N * a.P * a.Q;
-    hipLaunchKernelGGL((conv_smallc_kernel<T, R, C>), dim3(cdiv(M, 256)), dim3(256), 0, st, a);
+    FPD_LAUNCH((conv_smallc_kernel<T, R, C>), dim3(cdiv(M, 256)), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -278,8 +278,8 @@ int fpd_wgrad_smallc_launch(const fpd_wgrad_t& a, hipStream_t st) {
     if (!wgrad_smallc_domain(a)) return 1;
     const int ntiles = cdiv(a.N * a.P * a.Q, WS_TP);
     const int blocks = a.partial != nullptr ? wgrad_smallc_blocks(a) : 1;     // no slabs: one block owns every sum (deterministic, slow)
-    if (a.dtype == FPD_BF16) hipLaunchKernelGGL((wgrad_smallc_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a, ntiles);
-    else hipLaunchKernelGGL((wgrad_smallc_kernel<float>), dim3(blocks), dim3(256), 0, st, a, ntiles);
+    if (a.dtype == FPD_BF16) FPD_LAUNCH((wgrad_smallc_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a, ntiles);
+    else FPD_LAUNCH((wgrad_smallc_kernel<float>), dim3(blocks), dim3(256), 0, st, a, ntiles);
     return 0;
 }
 

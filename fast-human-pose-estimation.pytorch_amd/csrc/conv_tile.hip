@@ -73,7 +73,7 @@ static inline unsigned magic_of(int d) { return (unsigned)((0x100000000ull / (un
 // MFMA loop runs its 9 taps back to back behind ONE barrier instead of one barrier (and one exposed weight-load latency) per
 // tap -- these launches are latency-bound, LDS capacity is not a constraint for them.
 template <typename T, int TN, int BK, bool ALLW = false, bool FOLD = false>
-__device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGeo geo, const int dbg, const int bx, const int by) {
+__device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGeo geo, const int bx, const int by) {
     constexpr int VEC = DT<T>::VEC;
     constexpr int BNT = 32 * TN;
     constexpr int LD = BK + 16 / (int)sizeof(T);
@@ -266,17 +266,15 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
             *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
         }
     }
-    if (!(dbg & 8)) bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    bn_fill(a.bn, C, (double)M, s_scale, s_shift);
     if (FOLD && fold) {
         // dy = gamma*is*(g - m1 - xhat*m2), xhat = (u - mu)*is  ==  A g + B u + D   (coefficients formed in fp64);
         // the upper half of the block does it while the lower half fills the epilogue tables
         for (int c = tid - 128; c >= 0 && c < C; c += 128) {
             BnRaw r;
             bn_request(a.fold_bn, c, C, r);
-            const double b1 = stats_sum(a.fold_stats, C, c), b2 = stats_sum(a.fold_stats, C, C + c);
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { s1 += r.s[2 * q]; s2 += r.s[2 * q + 1]; }
+            const double b1 = stats_sum(a.fold_stats, C, 0, c), b2 = stats_sum(a.fold_stats, C, 1, c);
+            const double s1 = stat_resolve(r.s1), s2 = stat_resolve(r.s2);
             const double cnt = (double)M, mu = s1 / cnt;
             double var = s2 / cnt - mu * mu;
             if (var < 0.0) var = 0.0;
@@ -295,28 +293,26 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
 
     if constexpr (ALLW) {
         __syncthreads();                 // tables / zero fill visible to halo_store
-        if (!(dbg & 4)) halo_store(0);
+        halo_store(0);
         __syncthreads();
-        if (!(dbg & 2)) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int r = tap / 3, sx = tap - 3 * r;
-                const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
-                TapMma<T>::template run<TN, BK, LD>(sH + ab + sx * LD, sB + tap * BNT * LD, lane, acc);
-            }
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, sx = tap - 3 * r;
+            const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
+            TapMma<T>::template run<TN, BK, LD>(sH + ab + sx * LD, sB + tap * BNT * LD, lane, acc);
         }
     } else {
     for (int ch = 0; ch < nchunk; ++ch) {
         const int c0 = ch * BK;
         const bool more = ch + 1 < nchunk;
         __syncthreads();                 // previous chunk fully consumed (and, first time, tables/zero fill visible)
-        if (!(dbg & 4)) halo_store(c0);
+        halo_store(c0);
         b_store(0);
         __syncthreads();
         if (more) halo_load(c0 + BK);    // in flight during all taps of this chunk
         if (RS > 1) b_load(1, c0); else if (more) b_load(0, c0 + BK);
         int r = 0, s = 0;
-        for (int tap = 0; tap < ((dbg & 2) ? 0 : RS); ++tap) {
+        for (int tap = 0; tap < RS; ++tap) {
             const int ab = (r == 0) ? ab0 : ((r == 1) ? ab1 : ab2);
             TapMma<T>::template run<TN, BK, LD>(sH + ab + s * LD, sB + (tap & 1) * BNT * LD, lane, acc);
             if (tap + 1 < RS) {
@@ -328,7 +324,6 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
         }
     }
     }
-    if (dbg & 1) return;
     const int Mlim = min(M, m0 + TPX);   // rows of the 128-row MFMA tile beyond the tile's pixels belong to the next tile
     if (K % VEC == 0) {
         conv_epilogue_vec<T, TN>(a, acc, m0, n0, Mlim, s_epi, stage, s_red);   // starts with a barrier
@@ -339,8 +334,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
 }
 
 template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo, const int dbg) {
-    conv_tile_body<T, TN, BK, ALLW, FOLD>(a, geo, dbg, blockIdx.x, blockIdx.y);
+__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo) {
+    conv_tile_body<T, TN, BK, ALLW, FOLD>(a, geo, blockIdx.x, blockIdx.y);
 }
 
 // Two INDEPENDENT convolutions with the same tile configuration in one launch: pixel tiles [0, nbx_a) belong to `a`,
@@ -348,12 +343,12 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
 // bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
 template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const TileGeo logWa,
-                                                                const TileGeo logWb, const int nbx_a, const int dbg) {
+                                                                const TileGeo logWb, const int nbx_a) {
     // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
     // launch ends with a's normal tail instead of a's tail followed by b's
     const int nbx_b = (int)gridDim.x - nbx_a;
-    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK, ALLW, FOLD>(b, logWb, dbg, blockIdx.x, blockIdx.y);
-    else conv_tile_body<T, TN, BK, ALLW, FOLD>(a, logWa, dbg, (int)blockIdx.x - nbx_b, blockIdx.y);
+    if ((int)blockIdx.x < nbx_b) conv_tile_body<T, TN, BK, ALLW, FOLD>(b, logWb, blockIdx.x, blockIdx.y);
+    else conv_tile_body<T, TN, BK, ALLW, FOLD>(a, logWa, (int)blockIdx.x - nbx_b, blockIdx.y);
 }
 
 // FPD_CONV_ALLW: largest grid (blocks) that uses the all-taps-staged variant; 0 disables it
@@ -391,33 +386,19 @@ int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN + (a.epi == FPD_EPI_BNRELU_BWD ? 3 * a.C : 0)) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
     if (lds > LDS_MAX) return 1;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>), lds)) return rc_;
     dim3 grid(tiles_of(a), cdiv(a.K, 32 * TN));
-    static const int dbg = getenv("FPD_CONV_DBG") ? atoi(getenv("FPD_CONV_DBG")) : 0;   // ablation bits (timing experiments only)
-    static const int edbg = getenv("FPD_EPI_DBG") ? atoi(getenv("FPD_EPI_DBG")) : 0;    // epilogue ablation bits, travel in a._pad
-    fpd_conv_t ac = a;
-    ac._pad = edbg;
     if constexpr (TN <= 2) {
         if (a.fold_x != nullptr) {
-            static size_t configured_f = 0;
-            if (lds > configured_f) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-                configured_f = lds;
-            }
-            hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, ac, make_geo<T, BK>(a), dbg);
+            static LdsAttr configured_f;        // per device, set once (thread-safe: common.h)
+            if (int rc_ = configured_f.ensure(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW, true>), lds)) return rc_;
+            FPD_LAUNCH((conv_tile_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, a, make_geo<T, BK>(a));
             return 0;
         }
     }
     if (a.fold_x != nullptr) return fpd_fail(-2, "conv_tile: a folded BN-backward apply is compiled for TN <= 2 only (fpd_conv_fold_supported)");
-    hipLaunchKernelGGL((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, ac, make_geo<T, BK>(a), dbg);
+    FPD_LAUNCH((conv_tile_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, make_geo<T, BK>(a));
     return 0;
 }
 template <typename T, int TN, int BK>
@@ -464,30 +445,20 @@ int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     const size_t lds = (size_t)((bwd ? 5 : 2) * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) +
                        std::max({tile_lds<T, TN, BK, ALLW>(a), tile_lds<T, TN, BK, ALLW>(b), epi});
     if (lds > LDS_MAX) return 1;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>), lds)) return rc_;
     const int nbx_a = tiles_of(a), nbx_b = tiles_of(b);
     dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
     if constexpr (TN <= 2) {
         if (a.fold_x != nullptr || b.fold_x != nullptr) {
-            static size_t configured_f = 0;
-            if (lds > configured_f) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-                configured_f = lds;
-            }
-            hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a, 0);
+            static LdsAttr configured_f;        // per device, set once (thread-safe: common.h)
+            if (int rc_ = configured_f.ensure(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW, true>), lds)) return rc_;
+            FPD_LAUNCH((conv_tile_pair_kernel<T, TN, BK, ALLW, true>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a);
             return 0;
         }
     }
     if (a.fold_x != nullptr || b.fold_x != nullptr) return fpd_fail(-2, "conv_tile pair: a folded BN-backward apply is compiled for TN <= 2 only");
-    hipLaunchKernelGGL((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a, 0);
+    FPD_LAUNCH((conv_tile_pair_kernel<T, TN, BK, ALLW>), grid, dim3(256), lds, st, a, b, make_geo<T, BK>(a), make_geo<T, BK>(b), nbx_a);
     return 0;
 }
 template <typename T, int TN, int BK>

@@ -262,19 +262,14 @@ int launch_f8(const fpd_conv_t& a, const void* w8, const float* wscale, hipStrea
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN) * sizeof(float) + std::max(tile, epi);
     if (lds > LDS_MAX) return 1;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile_f8_kernel<TN, BK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_f8_kernel<TN, BK>), lds)) return rc_;
     TileGeo8 g;
     g.nrows = tile_rows(a.W);
     g.mW = magic_of(a.W);
     g.mWV = magic_of(a.W * (BK / 8));
     dim3 grid(cdiv(a.N * a.H, g.nrows), cdiv(a.K, 32 * TN));
-    hipLaunchKernelGGL((conv_tile_f8_kernel<TN, BK>), grid, dim3(256), lds, st, a, reinterpret_cast<const f8_t*>(w8), wscale, g);
+    FPD_LAUNCH((conv_tile_f8_kernel<TN, BK>), grid, dim3(256), lds, st, a, reinterpret_cast<const f8_t*>(w8), wscale, g);
     return 0;
 }
 
@@ -310,6 +305,6 @@ int fpd_conv_tile_f8_launch(const fpd_conv_t& a, const void* w8, const float* ws
 
 int fpd_weight_quant_f8_launch(const fpd_wquant_entry_t* table, int n, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(wquant_kernel, dim3(64, n), dim3(256), 0, st, table);
+    FPD_LAUNCH(wquant_kernel, dim3(64, n), dim3(256), 0, st, table);
     return 0;
 }

@@ -84,12 +84,12 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const fpd_warp_t a) {
 }  // namespace
 
 int fpd_render_targets_launch(const fpd_targets_t& a, hipStream_t st) {
-    hipLaunchKernelGGL(render_targets_kernel, dim3(a.B * a.J), dim3(256), 0, st, a);
+    FPD_LAUNCH(render_targets_kernel, dim3(a.B * a.J), dim3(256), 0, st, a);
     return 0;
 }
 
 int fpd_warp_affine_launch(const fpd_warp_t& a, hipStream_t st) {
     const int bx = std::min(cdiv(a.H * a.W, 256), 256);
-    hipLaunchKernelGGL(warp_affine_kernel, dim3(bx, a.B), dim3(256), 0, st, a);
+    FPD_LAUNCH(warp_affine_kernel, dim3(bx, a.B), dim3(256), 0, st, a);
     return 0;
 }

@@ -1,7 +1,7 @@
 // HBM-bound NHWC kernels of the hourglass graph and its backward: BN+ReLU, 2x2 max-pool, nearest x2
 // up-add, their gradients, BatchNorm-backward apply.  16-byte vectors along C, one vector per thread per
 // step, grid-stride over pixels; producers of a tensor that feeds a train-mode BN accumulate its
-// per-channel {sum, sum^2} (fp32 in registers -> LDS -> one fp64 atomic per channel per block).
+// per-channel {sum, sum^2} (fp64 in registers -> exact integer limbs in LDS -> one limb pair per sum, channel and block).
 // Replaces F.max_pool2d / nn.Upsample / nn.BatchNorm2d / nn.ReLU and their autograd in
 // /root/reference/lib/models/hourglass.py:80-92,172-177.
 #include <algorithm>
@@ -26,7 +26,7 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
     constexpr int VEC = DT<T>::VEC;
     __shared__ float s_t0[FPD_MAXC], s_t1[FPD_MAXC], s_t2[FPD_MAXC], s_t3[FPD_MAXC];
     __shared__ float s_is[FPD_MAXC];
-    __shared__ double s_sum[2][FPD_MAXC];   // fp64 statistics from the first add
+    __shared__ long long s_sum[4 * FPD_MAXC];   // [2 sums][2 limbs][C]: exact block accumulator of the statistics (common.h)
     const int tid = threadIdx.x;
     const int C = a.C, H = a.H, W = a.W, N = a.N;
     const int VP = C / VEC;              // vectors per pixel
@@ -48,7 +48,7 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
             bn_coef(a.bn, c, C, cnt, sc, sh, mu, is);
             if (OP == FPD_EW_BN_BWD_APPLY) {
                 s_t0[c] = a.bn.gamma[c] * is;                 // gamma * invstd
-                const double b1 = stats_sum(a.bstats, C, c), b2 = stats_sum(a.bstats, C, C + c);
+                const double b1 = stats_sum(a.bstats, C, 0, c), b2 = stats_sum(a.bstats, C, 1, c);
                 s_t1[c] = (float)(b1 / cnt);                  // mean(dz)
                 s_t2[c] = (float)(b2 / cnt);                  // mean(dz * xhat)
                 s_t3[c] = mu;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
         }
     }
     if (STATS || BSTATS)
-        for (int c = tid; c < C; c += 256) { s_sum[0][c] = 0.0; s_sum[1][c] = 0.0; }
+        for (int c = tid; c < 4 * C; c += 256) s_sum[c] = 0;
     __syncthreads();
 
     double acc1[VEC], acc2[VEC];
@@ -187,14 +187,11 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
     if (do_stats) {
         if (active) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { atomicAdd(&s_sum[0][cv + j], acc1[j]); atomicAdd(&s_sum[1][cv + j], acc2[j]); }
+            for (int j = 0; j < VEC; ++j) { stat_lds_add(s_sum, C, 0, cv + j, acc1[j]); stat_lds_add(s_sum, C, 1, cv + j, acc2[j]); }
         }
         __syncthreads();
-        double* dst = (STATS ? a.out_stats : a.bstats) + (size_t)stats_replica() * 2 * C;
-        for (int c = tid; c < C; c += 256) {
-            atomicAdd(dst + c, s_sum[0][c]);
-            atomicAdd(dst + C + c, s_sum[1][c]);
-        }
+        fpd_stat_t* dst = STATS ? a.out_stats : a.bstats;
+        for (int c = tid; c < C; c += 256) stat_flush_lds(dst, s_sum, C, c);
     }
 }
 
@@ -220,7 +217,7 @@ int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
                                                                                                    : OP == FPD_EW_BNRELU_BWD_R;
     const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
-    hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
+    FPD_LAUNCH((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -239,7 +236,7 @@ template <typename T>
 int launch_ew_pair(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st) {
     if (a.op != FPD_EW_BN_BWD_APPLY) return 1;                 // the only pairing the graph builder emits
     const int ga = ew_grid<T, FPD_EW_BN_BWD_APPLY>(a), gb = ew_grid<T, FPD_EW_BN_BWD_APPLY>(b);
-    hipLaunchKernelGGL((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
+    FPD_LAUNCH((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
     return 0;
 }
 
@@ -346,7 +343,7 @@ int fpd_affsum_launch(const fpd_affsum_t& a, hipStream_t st) {
         return fpd_fail(-3, "affsum: C=%d must be a multiple of %d and <= %d", a.C, vec, FPD_MAXC);
     const int PB = 256 / (a.C / vec);
     const int grid = std::max(1, std::min(cdiv(a.N * a.H * a.W, PB), 2048));
-    if (a.dtype == FPD_BF16) hipLaunchKernelGGL((affsum_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((affsum_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+    if (a.dtype == FPD_BF16) FPD_LAUNCH((affsum_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+    else FPD_LAUNCH((affsum_kernel<float>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }

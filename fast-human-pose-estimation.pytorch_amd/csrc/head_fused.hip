@@ -315,21 +315,16 @@ int fpd_head_fused_launch(const fpd_head_t& a, hipStream_t st) {
     if (!head_in_domain(a)) return 1;
     constexpr int C = 256, LDX = 72, LDA = C + 8;
     const size_t lds = (size_t)(3 * C + 32) * sizeof(float) + (size_t)128 * LDA * 2 + (size_t)128 * 24 * 2 + (size_t)2 * C * LDX * 2;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_eval_kernel<C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&head_eval_kernel<C>), lds)) return rc_;
     const int ntiles = cdiv(a.N * a.H * a.W, 128), cap = head_block_cap();
     const int nblk = ntiles <= cap ? ntiles : cdiv(ntiles, cdiv(ntiles, cap));
-    hipLaunchKernelGGL((head_eval_kernel<C>), dim3(nblk), dim3(512), lds, st, a, ntiles);
+    FPD_LAUNCH((head_eval_kernel<C>), dim3(nblk), dim3(512), lds, st, a, ntiles);
     return 0;
 }
 
 int fpd_head_fold_launch(const fpd_head_t& a, float* out, hipStream_t st) {
     if (a.C != 256) return 1;
-    hipLaunchKernelGGL((head_fold_kernel<256>), dim3(1), dim3(256), 0, st, a, out);
+    FPD_LAUNCH((head_fold_kernel<256>), dim3(1), dim3(256), 0, st, a, out);
     return 0;
 }

@@ -81,18 +81,18 @@ __global__ __launch_bounds__(256) void final_preds_kernel(const fpd_finalpreds_t
 int fpd_flip_w_launch(const float* x, float* y, int64_t rows, int W, hipStream_t st) {
     const int64_t total = rows * W;
     const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-    hipLaunchKernelGGL(flip_w_kernel, dim3(blocks), dim3(256), 0, st, x, y, rows, W);
+    FPD_LAUNCH(flip_w_kernel, dim3(blocks), dim3(256), 0, st, x, y, rows, W);
     return 0;
 }
 
 int fpd_flip_merge_launch(const fpd_flipmerge_t& p, hipStream_t st) {
     const int64_t total = (int64_t)p.N * p.J * p.H * p.W;
     const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-    hipLaunchKernelGGL(flip_merge_kernel, dim3(blocks), dim3(256), 0, st, p);
+    FPD_LAUNCH(flip_merge_kernel, dim3(blocks), dim3(256), 0, st, p);
     return 0;
 }
 
 int fpd_final_preds_launch(const fpd_finalpreds_t& p, hipStream_t st) {
-    hipLaunchKernelGGL(final_preds_kernel, dim3(p.N * p.J), dim3(256), 0, st, p);
+    FPD_LAUNCH(final_preds_kernel, dim3(p.N * p.J), dim3(256), 0, st, p);
     return 0;
 }

@@ -59,9 +59,13 @@ __global__ __launch_bounds__(256) void loss_kernel(const fpd_loss_t a) {
     if (lane == 0) { s_acc[0][wave] = dp; s_acc[1][wave] = dk; }
     __syncthreads();
     if (tid == 0) {
-        const double sc = 0.5 / cnt;
-        atomicAdd(a.losses + 0, sc * (s_acc[0][0] + s_acc[0][1] + s_acc[0][2] + s_acc[0][3]));
-        atomicAdd(a.losses + 1, sc * (s_acc[1][0] + s_acc[1][1] + s_acc[1][2] + s_acc[1][3]));
+        // Order-independent sum over the blocks (bit-repeatable losses): every contribution is rounded to a multiple of
+        // 2^-44 (5.7e-14), so the fp64 additions are EXACT while the loss stays below 2^9 -- whatever order they arrive in.
+        const double sc = 0.5 / cnt, q = 17592186044416.0;     // 2^44
+        const double vp = sc * (s_acc[0][0] + s_acc[0][1] + s_acc[0][2] + s_acc[0][3]);
+        const double vk = sc * (s_acc[1][0] + s_acc[1][1] + s_acc[1][2] + s_acc[1][3]);
+        atomicAdd(a.losses + 0, rint(vp * q) / q);
+        atomicAdd(a.losses + 1, rint(vk * q) / q);
     }
 }
 
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void wprep_kernel(const fpd_wprep_entry_t* tab
 __global__ __launch_bounds__(256) void bnupd_kernel(const fpd_bnupd_entry_t* table) {
     const fpd_bnupd_entry_t e = table[blockIdx.x];
     for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-        const double mean = stats_sum(e.stats, e.C, c) / e.count;
-        double var = stats_sum(e.stats, e.C, e.C + c) / e.count - mean * mean;
+        const double mean = stats_sum(e.stats, e.C, 0, c) / e.count;
+        double var = stats_sum(e.stats, e.C, 1, c) / e.count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double unb = e.count > 1.0 ? var * e.count / (e.count - 1.0) : var;
         e.running_mean[c] = (float)((1.0 - e.momentum) * (double)e.running_mean[c] + e.momentum * mean);
@@ -153,15 +157,15 @@ int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st) {
     if (a.J > 32 || a.S > FPD_MAX_STACKS || a.S < 1) return fpd_fail(-3, "loss: J=%d (<=32), S=%d (1..%d)", a.J, a.S, FPD_MAX_STACKS);
     const int tiles = a.B * cdiv(a.H * a.W, 64);
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((loss_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);
+        FPD_LAUNCH((loss_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((loss_kernel<float>), dim3(tiles), dim3(256), 0, st, a);
+        FPD_LAUNCH((loss_kernel<float>), dim3(tiles), dim3(256), 0, st, a);
     return 0;
 }
 
 int fpd_adam_launch(const fpd_adam_t& a, hipStream_t st) {
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n)), dim3(256), 0, st, a);
-    if (a.step_dev != nullptr) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, a.step_dev);
+    FPD_LAUNCH(adam_kernel, dim3(grid_for(a.n)), dim3(256), 0, st, a);
+    if (a.step_dev != nullptr) FPD_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, st, a.step_dev);
     return 0;
 }
 
@@ -169,45 +173,45 @@ int fpd_weight_prep_launch(const fpd_wprep_entry_t* table, int n, int64_t max_el
     if (n <= 0) return 0;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems + 255) / 256, 256)), (unsigned)n);
     if (dtype == FPD_BF16)
-        hipLaunchKernelGGL((wprep_kernel<bf16_t>), grid, dim3(256), 0, st, table);
+        FPD_LAUNCH((wprep_kernel<bf16_t>), grid, dim3(256), 0, st, table);
     else
-        hipLaunchKernelGGL((wprep_kernel<float>), grid, dim3(256), 0, st, table);
+        FPD_LAUNCH((wprep_kernel<float>), grid, dim3(256), 0, st, table);
     return 0;
 }
 
 int fpd_bn_update_running_launch(const fpd_bnupd_entry_t* table, int n, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(bnupd_kernel, dim3(n), dim3(256), 0, st, table);
+    FPD_LAUNCH(bnupd_kernel, dim3(n), dim3(256), 0, st, table);
     return 0;
 }
 
 int fpd_cast_launch(const void* src, void* dst, int64_t n, int sd, int dd, hipStream_t st) {
     const int g = grid_for(n);
     if (sd == FPD_F32 && dd == FPD_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+        FPD_LAUNCH((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
     else if (sd == FPD_BF16 && dd == FPD_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+        FPD_LAUNCH((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
     else if (sd == FPD_F32 && dd == FPD_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+        FPD_LAUNCH((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n);
     else
-        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+        FPD_LAUNCH((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
     return 0;
 }
 
 int fpd_nchw_to_nhwc_launch(const float* src, void* dst, int N, int C, int H, int W, int dtype, hipStream_t st) {
     const int g = grid_for((int64_t)N * C * H * W);
     if (dtype == FPD_BF16)
-        hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, N, C, H, W);
+        FPD_LAUNCH((nchw_to_nhwc_kernel<bf16_t>), dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, N, C, H, W);
     else
-        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(g), dim3(256), 0, st, src, (float*)dst, N, C, H, W);
+        FPD_LAUNCH((nchw_to_nhwc_kernel<float>), dim3(g), dim3(256), 0, st, src, (float*)dst, N, C, H, W);
     return 0;
 }
 
 int fpd_nhwc_to_nchw_launch(const void* src, float* dst, int N, int C, int H, int W, int dtype, hipStream_t st) {
     const int g = grid_for((int64_t)N * C * H * W);
     if (dtype == FPD_BF16)
-        hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, H, W);
+        FPD_LAUNCH((nhwc_to_nchw_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, H, W);
     else
-        hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, dst, N, C, H, W);
+        FPD_LAUNCH((nhwc_to_nchw_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, dst, N, C, H, W);
     return 0;
 }

@@ -67,8 +67,8 @@ __global__ void pck_finish_kernel(const fpd_pck_t a) {
 }  // namespace
 
 int fpd_pck_launch(const fpd_pck_t& a, hipStream_t st) {
-    if (a.dtype == FPD_BF16) hipLaunchKernelGGL(pck_kernel<bf16_t>, dim3(a.B * a.J), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(pck_kernel<float>, dim3(a.B * a.J), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(pck_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    if (a.dtype == FPD_BF16) FPD_LAUNCH(pck_kernel<bf16_t>, dim3(a.B * a.J), dim3(256), 0, st, a);
+    else FPD_LAUNCH(pck_kernel<float>, dim3(a.B * a.J), dim3(256), 0, st, a);
+    FPD_LAUNCH(pck_finish_kernel, dim3(1), dim3(64), 0, st, a);
     return 0;
 }

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const fpd_stem_t a) {
             const int py = ty0 + p / TW, px = tx0 + p % TW;
             if (py < P && px < Q) { const double v = (double)buf[p * LDO + tid]; s1 += v; s2 += v * v; }
         }
-        atomicAdd(a.out_stats + stats_replica() * 2 * K + tid, s1);
-        atomicAdd(a.out_stats + stats_replica() * 2 * K + K + tid, s2);
+        stat_atomic_add(a.out_stats, K, 0, tid, s1);
+        stat_atomic_add(a.out_stats, K, 1, tid, s2);
     }
 }
 
@@ -154,9 +154,9 @@ int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st) {
     if (a.K > KMAX || a.K < 1) return fpd_fail(-3, "stem: K=%d unsupported (1..%d)", a.K, KMAX);
     const int tiles = a.N * cdiv(a.P, TH) * cdiv(a.Q, TW);
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);
+        FPD_LAUNCH((stem_fwd_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3(tiles), dim3(256), 0, st, a);
+        FPD_LAUNCH((stem_fwd_kernel<float>), dim3(tiles), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -170,8 +170,8 @@ int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st) {
     const int tiles = a.N * cdiv(a.P, TH) * cdiv(a.Q, TW);
     const int grid = a.partial != nullptr ? std::min(tiles, 1024) : 1;
     if (a.dtype == FPD_BF16)
-        hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, tiles);
+        FPD_LAUNCH((stem_wgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, tiles);
     else
-        hipLaunchKernelGGL((stem_wgrad_kernel<float>), dim3(grid), dim3(256), 0, st, a, tiles);
+        FPD_LAUNCH((stem_wgrad_kernel<float>), dim3(grid), dim3(256), 0, st, a, tiles);
     return 0;
 }

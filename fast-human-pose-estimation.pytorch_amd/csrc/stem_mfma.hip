@@ -274,10 +274,10 @@ int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     static bool cfg1 = false, cfg2 = false;
     if (TN == 1) {
         if (!cfg1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg1 = true; }
-        hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(tiles), dim3(256), lds, st, a, logQ);
+        FPD_LAUNCH((stem_fwd_mfma_kernel<1>), dim3(tiles), dim3(256), lds, st, a, logQ);
     } else {
         if (!cfg2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg2 = true; }
-        hipLaunchKernelGGL((stem_fwd_mfma_kernel<2>), dim3(tiles), dim3(256), lds, st, a, logQ);
+        FPD_LAUNCH((stem_fwd_mfma_kernel<2>), dim3(tiles), dim3(256), lds, st, a, logQ);
     }
     return 0;
 }
@@ -295,6 +295,6 @@ int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     const int tiles = a.N * a.P * a.Q / 128;
     static bool cfg = false;
     if (!cfg) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg = true; }
-    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(a.partial != nullptr ? std::min(tiles, 512) : 1), dim3(256), lds, st, a, logQ, tiles);
+    FPD_LAUNCH(stem_wgrad_mfma_kernel, dim3(a.partial != nullptr ? std::min(tiles, 512) : 1), dim3(256), lds, st, a, logQ, tiles);
     return 0;
 }

@@ -55,7 +55,7 @@ struct WFrag<float> {
 // is live, so the nine taps -- not 9 x 4 sub-tiles, three quarters of them zero -- are spread over the waves.
 template <typename T, int R, int TP, bool H4, bool SMALL = false>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, const int nrows, const unsigned mW, const int ctiles,
-                                                         const int mtiles, const int dbg) {
+                                                         const int mtiles) {
     using WF = WFrag<T>;
     constexpr int VEC = DT<T>::VEC;
     constexpr int CW = 128 / (int)sizeof(T);          // channels per tile row: 64 (bf16) / 32 (fp32) = 128 bytes
@@ -211,10 +211,10 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     if (tile < mtiles) loads(tile);
     for (; tile < mtiles; tile += gridDim.x) {
         __syncthreads();                    // previous tile consumed (first time: zero fill + tables visible)
-        if (!(dbg & 4)) stores();
+        stores();
         __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < mtiles && !(dbg & 8)) loads(next);     // in flight during this tile's MFMAs
+        if (next < mtiles) loads(next);     // in flight during this tile's MFMAs
         const int g0 = tile * nrows;
         if (do_bias) {
             float s0 = 0.f, s1 = 0.f;
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
                 for (int i = 0; i < NS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.f, bf[i], acc[i], 0, 0, 0);
             }
         };
-        if (dbg & 2) continue;
         if (H4) {
 #pragma unroll 1
             for (int pix0 = 0; pix0 < TPX; pix0 += KSTEP) kstep4(pix0);
@@ -298,7 +297,6 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const fpd_wgrad_t a, co
     // fpd_wgrad_reduce() adds the slabs in a fixed order; without slabs the launch has ONE block per (k, c) tile
     // (gridDim.x == 1, see fpd_wgrad_tile_launch), which owns its dw / dbias elements and adds to them directly.
     // Either way a weight gradient is a fixed-order sum: identical bytes run to run.
-    if (dbg & 1) return;
     const bool slabs = a.partial != nullptr;
     if (KSPLIT && !slabs) {
         // the two wave groups hold partial sums of the SAME elements: group 1 hands its accumulator over through LDS
@@ -396,16 +394,10 @@ int launch_wt(const fpd_wgrad_t& a, const WtGrid& g, hipStream_t st) {
     constexpr int LD = CW + 16 / (int)sizeof(T);
     const int hrows = g.nrows + a.R - 1, WP = a.W + a.R - 1;
     const size_t lds = 2 * CW * sizeof(float) + (size_t)(hrows * WP + TP + 16) * LD * sizeof(T);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP, H4, SMALL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fpd_fail(-100 - (int)e, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-        configured = lds;
-    }
-    static const int dbg = getenv("FPD_WGRAD_DBG") ? atoi(getenv("FPD_WGRAD_DBG")) : 0;   // ablation bits (timing experiments only)
-    hipLaunchKernelGGL((wgrad_tile_kernel<T, R, TP, H4, SMALL>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
-                       (unsigned)((0x100000000ull / (unsigned long long)a.W) + 1ull), g.ctiles, g.mtiles, dbg);
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&wgrad_tile_kernel<T, R, TP, H4, SMALL>), lds)) return rc_;
+    FPD_LAUNCH((wgrad_tile_kernel<T, R, TP, H4, SMALL>), dim3(g.gx, g.gy), dim3(512), lds, st, a, g.nrows,
+                       (unsigned)((0x100000000ull / (unsigned long long)a.W) + 1ull), g.ctiles, g.mtiles);
     return 0;
 }
 
@@ -456,6 +448,6 @@ int fpd_wgrad_tile_partials(const fpd_wgrad_t& a) {
 int fpd_wreduce_launch(const fpd_wreduce_entry_t* table, int n, int64_t max_elems, hipStream_t st) {
     if (n <= 0) return 0;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_elems / 4 + 255) / 256, 64)), (unsigned)n);
-    hipLaunchKernelGGL(wreduce_kernel, grid, dim3(256), 0, st, table);
+    FPD_LAUNCH(wreduce_kernel, grid, dim3(256), 0, st, table);
     return 0;
 }

@@ -17,7 +17,7 @@ _EW = {'bnrelu_fwd': R.EW_BNRELU_FWD, 'bnrelu_bwd_r': R.EW_BNRELU_BWD_R, 'bn_bwd
        'maxpool_fwd': R.EW_MAXPOOL_FWD, 'maxpool_bwd': R.EW_MAXPOOL_BWD, 'upadd_fwd': R.EW_UPADD_FWD,
        'sumpool': R.EW_SUMPOOL, 'add': R.EW_ADD, 'relu_mask': R.EW_RELU_MASK, 'dilate2': R.EW_DILATE2}
 _ARENA_DTYPE = {'param': torch.float32, 'grad': torch.float32, 'rstat': torch.float32, 'nbt': torch.int64,
-                'stats': torch.float64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
+                'stats': torch.int64, 'losses': torch.float64, 'image': torch.float32, 'target': torch.float32,
                 'weight': torch.float32, 'adam_m': torch.float32, 'adam_v': torch.float32, 'fold': torch.float32,
                 'w8': torch.uint8, 'w8s': torch.float32}
 
@@ -26,8 +26,15 @@ def act_torch_dtype(dtype):
     return torch.bfloat16 if dtype == R.BF16 else torch.float32
 
 
+_STAT_HI, _STAT_LO = 256.0, float(2 ** 60)      # include/fpd_amd.h fpd_stat_t: value = hi * 2^-8 + lo * 2^-60
+
+
 class Arenas:
-    """name -> flat device tensor.  Lookups fall through to `parent` (model-level arenas)."""
+    """name -> flat device tensor.  Lookups fall through to `parent` (model-level arenas).
+
+    The 'stats' arena holds the exact statistics of include/fpd_amd.h (fpd_stat_t): the IR sizes a buffer over C channels
+    as [R][2][C] logical values (what the CPU interpreter keeps as doubles); on the device every logical value is TWO
+    64-bit integer limbs, laid out [R][2 sums][2 limbs][C], so the arena has two words per IR element."""
 
     def __init__(self, device, dtype, parent=None):
         self.device, self.dtype, self.parent = device, dtype, parent
@@ -35,8 +42,21 @@ class Arenas:
 
     def alloc(self, name, n):
         dt = _ARENA_DTYPE.get(name, act_torch_dtype(self.dtype))
-        self.t[name] = torch.zeros(max(int(n), 4), dtype=dt, device=self.device)
+        n = max(int(n), 4) * (2 if name == 'stats' else 1)
+        self.t[name] = torch.zeros(n, dtype=dt, device=self.device)
         return self.t[name]
+
+    def stats_read(self, buf):
+        """[R][2][C] float64: the value of every (replica, sum, channel) of a statistics buffer (a copy)."""
+        raw = self.view(buf)
+        return raw[:, :, 0, :].double() / _STAT_HI + raw[:, :, 1, :].double() / _STAT_LO
+
+    def stats_write(self, buf, values):
+        """Store [R][2][C] float64 values into a statistics buffer (the split a kernel's contribution goes through)."""
+        v = values.to(self.device, torch.float64).reshape(buf.shape)
+        hi = torch.round(v * _STAT_HI)
+        lo = torch.round((v - hi / _STAT_HI) * _STAT_LO)
+        self.view(buf).copy_(torch.stack([hi.to(torch.int64), lo.to(torch.int64)], 2))
 
     def tensor(self, name):
         if name in self.t:
@@ -49,9 +69,12 @@ class Arenas:
         if buf is None:
             return None
         t = self.tensor(buf.arena)
-        return t.data_ptr() + buf.off * t.element_size()
+        return t.data_ptr() + buf.off * t.element_size() * (2 if buf.arena == 'stats' else 1)
 
     def view(self, buf):
+        if buf.arena == 'stats':                   # raw limbs [R][2 sums][2 limbs][C]
+            r, two, c = buf.shape
+            return self.tensor('stats')[2 * buf.off:2 * (buf.off + buf.numel)].view(r, two, 2, c)
         return self.tensor(buf.arena)[buf.off:buf.off + buf.numel].view(buf.shape)
 
 
@@ -65,6 +88,10 @@ def _abuf(a):
 # nobigconv (convolutions on >= 64x64 maps), nobig / nomid / nosmall (every op on >= 64 / 32 / <= 16 high maps, weight
 # gradients excepted), noew.  Teacher graph: t_all, t_big, t_mid, t_small.
 _WHATIF = frozenset(t for t in os.environ.get('FPD_WHATIF', '').split(',') if t)
+if _WHATIF:
+    import sys
+    sys.stderr.write('[fpd_amd] WARNING: FPD_WHATIF=%s is set: op classes are dropped from the plans -- TIMING ONLY, every result '
+                     '(maps, losses, gradients, parameters) of this process is WRONG\n' % ','.join(sorted(_WHATIF)))
 
 
 def _whatif_drop(op, train):
@@ -127,7 +154,7 @@ class Lowering:
         s.out_stats = p(op.out_stats)
         s.bn = self.bn(op.bn)
         s.epi_x, s.epi_bn, s.epi_stats = p(_abuf(op.epi_x)), self.bn(op.epi_bn), p(op.epi_stats)
-        s.wg_partial, s.wg_stride, s.wg_bias = None, 0, 0
+        s.wg_partial, s.wg_stride, s.wg_bias, s.wg_count = None, 0, 0, 0
         if not plain and getattr(op, 'fused_wgrad', None) is not None and self.use_partials:
             n = R.lib().fpd_conv_fused_wgrad_partials(C.byref(s))
             if n > 0:
@@ -147,12 +174,33 @@ class Lowering:
         if os.environ.get('FPD_FOLD_APPLY', '1') == '0':
             return
         l = R.lib()
-        for op in ops:
+        members_of = lambda top: [m for m in ((top.a, top.b) if top.kind in ('conv2', 'ew2', 'bneck2') else (top,)) if m is not None]
+        for i, op in enumerate(ops):
             if op is None or op.kind not in ('conv', 'conv2'):
                 continue
-            members = [m for m in ((op.a, op.b) if op.kind == 'conv2' else (op,)) if m is not None]
+            members = members_of(op)
             cands = [m for m in members if getattr(m, 'fold_apply', None) is not None and not getattr(m.fold_apply, 'folded', False)]
             if not cands or any(getattr(m, 'w8', None) is not None for m in members):
+                continue
+            # Who else reads an apply's result?  Its own convolution's weight gradient is served from the launch's operand image
+            # when that is fused too; ANY other reader (a tensor aliased into a residual-path gradient, an op on another lane)
+            # needs the evaluated operand in memory: the launch then writes it out (fold_out).  A reader that comes BEFORE the
+            # convolution in the list would read it before it exists: no fold.
+            early = False
+            for m in cands:
+                y = _abuf(m.fold_apply.y)
+                own = (id(m), id(m.fold_apply), id(getattr(m, 'fold_wgrad', None)))
+                m.fold_other_readers = False
+                for j, top in enumerate(ops):
+                    if top is None:
+                        continue
+                    for o in members_of(top):
+                        if id(o) in own or not any(_abuf(t) is y for t in o.acts_in()):
+                            continue
+                        if j < i:
+                            early = True
+                        m.fold_other_readers = True
+            if early:
                 continue
             if op.kind == 'conv2':
                 ps = R.ConvPairT()
@@ -175,7 +223,8 @@ class Lowering:
         s.fold_x, s.fold_bn, s.fold_stats = p(_abuf(ap.x)), self.bn(ap.bn), p(ap.bstats)
         s.fold_dgamma, s.fold_dbeta = p(ap.dgamma), p(ap.dbeta)
         # its other consumer -- the convolution's weight gradient -- reads the evaluated operand unless it is formed right here
-        s.fold_out = None if getattr(op, 'fused_active', False) else p(_abuf(ap.y))
+        skip = getattr(op, 'fused_active', False) and not getattr(op, 'fold_other_readers', False)
+        s.fold_out = None if skip else p(_abuf(ap.y))
 
     def _fuse_wgrad(self, op, s, n):
         """The data-gradient launch `op` (struct `s`, a ConvT -- possibly a field of a pair struct) also forms the weight
@@ -188,6 +237,7 @@ class Lowering:
         self.partials[id(fw)] = [s, fw.dw, numel, stride, n, self.partial_elems, fw.dbias, s.C]
         self.partial_elems += n * stride
         s.wg_bias = 1 if fw.dbias is not None else 0
+        s.wg_count = n                                      # the launch refuses a geometry that writes another number of slabs
         self.fused.add(id(fw))
         op.fused_active = True
 
@@ -575,7 +625,7 @@ class GraphInstance:
         assert self.train
         torch.cuda.synchronize()
         for bn in self.g.bns:
-            st = self.A.view(bn.stats).sum(0)
+            st = self.A.stats_read(bn.stats).sum(0)
             mean = st[0] / bn.count
             var = (st[1] / bn.count - mean * mean).clamp_min(0) * (bn.count / max(bn.count - 1, 1))
             self.A.view(bn.rmean).copy_(mean.float())
@@ -632,6 +682,8 @@ class FusedFPDStep:
             self.ev_t = [torch.cuda.Event(), torch.cuda.Event()]
             self.ev_chunk = [torch.cuda.Event() for _ in range(teacher_chunks)]
         self._k_t = self._k_s = 0
+        # 'loss' (default): the student step waits for the teacher's map in front of the fused loss; 'start': before its forward
+        self._late_teacher_wait = os.environ.get('FPD_TEACHER_WAIT', 'loss') == 'loss'
         self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True)
         g = self.student.g
         self.hh, self.hw = g.outputs[0].shape[1:3]
@@ -753,7 +805,7 @@ class FusedFPDStep:
         """Student prep/forward, fused loss (against the staged teacher map), backward, [all-reduce], Adam."""
         s = self.student
         slot = self._k_s % 2
-        late = os.environ.get('FPD_TEACHER_WAIT', 'loss') == 'loss'
+        late = self._late_teacher_wait
         if self.teacher is not None:
             assert self._k_t > self._k_s, 'teacher_async() must be submitted before student_step()'
             if not late:

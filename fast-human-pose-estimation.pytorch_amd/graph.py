@@ -118,8 +118,9 @@ class Op:
             fw = getattr(self, 'fused_wgrad', None)        # this data gradient also writes the slabs of that weight gradient
             if fw is not None and getattr(self, 'fused_active', False):
                 wr += [fw.dw, fw.dbias]
-            fa = getattr(self, 'fold_apply', None)         # it may evaluate that BN-backward apply itself (executor decides):
-            if fa is not None:                             # then it reads the apply's inputs and writes its outputs
+            fa = getattr(self, 'fold_apply', None)         # it may evaluate that BN-backward apply itself (executor decides,
+            if fa is not None and getattr(self, 'fold_active', False):     # before the schedule is built): then it reads the
+                # apply's inputs and writes its outputs
                 rd += [b(fa.x), b(fa.dy), fa.bstats] + bn_bufs(fa.bn)
                 wr += [b(fa.y), fa.dgamma, fa.dbeta]
         elif k == 'head':
@@ -797,7 +798,7 @@ class HourglassGraph:
                 # weight gradient: the data gradient may evaluate the apply on its operand load (fpd_conv_t.fold_x) and the
                 # separate launch becomes a no-op -- decided at lowering time like the fused weight gradient
                 ap = getattr(op.y.grad, 'apply_op', None)
-                if FOLD_APPLY and ap is not None and stride == 1 and dy is op.y.grad and (ap.lane or 0) == (d.lane or 0):
+                if FOLD_APPLY and ap is not None and stride == 1 and dy is op.y.grad and (ap.lane or 0) == (self._lane or 0):      # (the lane d is about to be stamped with)
                     d.fold_apply = ap
                     d.fold_wgrad = wg
                 self._emit_dgrad(d)

@@ -35,7 +35,7 @@ class ConvT(C.Structure):
                 ('stride', _i32), ('pad', _i32), ('P', _i32), ('Q', _i32), ('dtype', _i32), ('epi', _i32),
                 ('_pad', _i32), ('x', _vp), ('w', _vp), ('bias', _vp), ('residual', _vp), ('y', _vp),
                 ('out_stats', _vp), ('bn', BnT), ('epi_x', _vp), ('epi_bn', BnT), ('epi_stats', _vp),
-                ('wg_partial', _vp), ('wg_stride', _i64), ('wg_bias', _i32), ('_pad2', _i32),
+                ('wg_partial', _vp), ('wg_stride', _i64), ('wg_bias', _i32), ('wg_count', _i32),
                 ('fold_x', _vp), ('fold_bn', BnT), ('fold_stats', _vp), ('fold_out', _vp), ('fold_dgamma', _vp), ('fold_dbeta', _vp)]
 
 

@@ -13,7 +13,7 @@
  *   - every call is asynchronous on the given hipStream_t, never synchronises, never allocates;
  *   - return 0 on success, negative on error; fpd_last_error() gives a thread-local message;
  *   - activations are NHWC ("channels last"), dtype FPD_F32 or FPD_BF16; conv weights are
- *     K,R,S,C (the reference's OIHW tensor stored channels-last); statistics are fp64.
+ *     K,R,S,C (the reference's OIHW tensor stored channels-last); statistics are exact fixed-point sums (fpd_stat_t).
  */
 #ifndef FPD_AMD_H
 #define FPD_AMD_H
@@ -29,11 +29,20 @@ typedef void* fpd_stream_t; /* hipStream_t */
 
 enum { FPD_F32 = 0, FPD_BF16 = 1 };
 /* Every per-channel statistics buffer (BN forward {sum, sumsq}; BN backward {sum dz, sum dz*xhat}) holds
- * FPD_STATS_REPLICAS independent partial copies: layout [R][2][C] fp64.  Producer block b adds into replica b % R
- * (thousands of blocks adding into ONE address serialise at ~12 ns per atomic); consumers sum the replicas. */
+ * FPD_STATS_REPLICAS independent partial copies.  Producer block b adds into replica b % R (thousands of blocks adding
+ * into ONE address serialise at ~20 ns per atomic); consumers sum the replicas.
+ * The sums are EXACT and therefore independent of the order in which the blocks' contributions arrive (a training step
+ * is bit-repeatable): a block's fp64 partial v is added as two 64-bit INTEGER limbs
+ *     hi = rint(v * 2^8)                      units of 2^-8   (|v| clamped to 2^54)
+ *     lo = rint((v - hi * 2^-8) * 2^60)       units of 2^-60  (|lo| <= 2^51)
+ * with integer atomics (associative, unlike floating-point ones; measured on MI355X: same cost as an fp64 atomic pair),
+ * value = hi * 2^-8 + lo * 2^-60.  Layout of one buffer over C channels: fpd_stat_t [R][2 sums][2 limbs: hi, lo][C]
+ * (FPD_STATS_WORDS(C) 64-bit words); the caller zeroes it (all-zero bytes = all-zero sums). */
 #ifndef FPD_STATS_REPLICAS
 #define FPD_STATS_REPLICAS 4
 #endif
+typedef int64_t fpd_stat_t;
+#define FPD_STATS_WORDS(C) ((int64_t)FPD_STATS_REPLICAS * 4 * (C))
 enum { FPD_BN_NONE = 0, FPD_BN_TRAIN = 1, FPD_BN_EVAL = 2 };
 enum { FPD_EPI_PLAIN = 0, FPD_EPI_BNRELU_BWD = 1 };
 enum { FPD_BACKEND_MFMA = 0, FPD_BACKEND_NAIVE = 1, FPD_BACKEND_MFMA_GENERIC = 2 };
@@ -49,7 +58,7 @@ typedef struct {
     int32_t relu;          /* apply ReLU after the affine (hourglass.py:28) */
     float eps;
     int32_t _pad;
-    const double* stats;   /* TRAIN: [R][2][C] sum, sum of squares over N*H*W (R = FPD_STATS_REPLICAS) */
+    const fpd_stat_t* stats; /* TRAIN: statistics buffer over C: sum, sum of squares over N*H*W (layout: fpd_stat_t above) */
     const float* gamma;    /* [C] */
     const float* beta;     /* [C] */
     const float* running_mean; /* EVAL: [C] */
@@ -75,11 +84,11 @@ typedef struct {
     const float* bias;     /* [K] or NULL */
     const void* residual;  /* [N,P,Q,K] or NULL (may alias y) */
     void* y;
-    double* out_stats;     /* [R][2][K] += {sum y, sum y^2} or NULL */
+    fpd_stat_t* out_stats; /* statistics buffer over K += {sum y, sum y^2}, or NULL */
     fpd_bn_t bn;           /* prologue on x (mode NONE = raw x) */
     const void* epi_x;     /* BNRELU_BWD: forward tensor normalised by epi_bn, [N,P,Q,K] */
     fpd_bn_t epi_bn;       /* BNRELU_BWD: its (train-mode) BN */
-    double* epi_stats;     /* BNRELU_BWD: [R][2][K] += {sum dz, sum dz*xhat} */
+    fpd_stat_t* epi_stats; /* BNRELU_BWD: statistics buffer over K += {sum dz, sum dz*xhat} */
     /* FUSED WEIGHT GRADIENT (optional; BNRELU_BWD data gradient of a 1x1 convolution only): this launch is the data gradient
      * of a forward convolution y = W * a(u), a(u) = relu?(bn(u)); it reads x = dy and epi_x = u anyway, so it can form the
      * forward convolution's weight gradient dW[k][c] = sum_pixels dy[.,k] * a(u)[.,c] (k < C of this launch, c < K of this
@@ -90,7 +99,9 @@ typedef struct {
     float* wg_partial;
     int64_t wg_stride;     /* floats between slabs, >= C*K + C */
     int32_t wg_bias;       /* also accumulate the bias gradient */
-    int32_t _pad2;
+    int32_t wg_count;      /* slabs the caller provided behind wg_partial = what fpd_conv_fused_wgrad_partials() returned when the
+                            * workspace was sized; the launch fails (instead of writing past it) if its geometry has changed since
+                            * -- e.g. fpd_set_option("conv_pp_blocks") between the query and the launch */
     /* FOLDED BN-BACKWARD APPLY (optional; BNRELU_BWD data gradients served by the persistent kernel only, bn.mode NONE): x is
      * not the operand itself but the masked gradient g that reached a train-mode BatchNorm whose input was fold_x = u, with
      * the two sums {sum g, sum g*xhat} in fold_stats.  The launch evaluates the BN backward on the way into its operand image,
@@ -101,7 +112,7 @@ typedef struct {
      * whether a launch is served (0: leave fold_x NULL and issue the apply). */
     const void* fold_x;
     fpd_bn_t fold_bn;
-    const double* fold_stats;
+    const fpd_stat_t* fold_stats;
     void* fold_out;
     float* fold_dgamma;
     float* fold_dbeta;
@@ -190,7 +201,7 @@ typedef struct {
     const float* w;        /* [K][7][7][3] fp32 */
     const float* bias;     /* [K] */
     void* y;               /* [N,P,Q,K] */
-    double* out_stats;     /* [R][2][K] or NULL */
+    fpd_stat_t* out_stats; /* statistics buffer over K, or NULL */
     const void* dy;        /* wgrad: [N,P,Q,K] */
     float* dw;             /* wgrad: [K][7][7][3] */
     float* dbias;          /* wgrad: [K] */
@@ -226,8 +237,8 @@ typedef struct {
     const void* dy;
     const void* add;       /* optional accumulate source (may alias y) */
     void* y;
-    double* out_stats;     /* [R][2][C] or NULL */
-    double* bstats;        /* BN-backward sums [R][2][C] */
+    fpd_stat_t* out_stats; /* statistics buffer over C, or NULL */
+    fpd_stat_t* bstats;    /* BN-backward sums: statistics buffer over C */
     float* dgamma;         /* BN_BWD_APPLY: optional [C] <- sum dz*xhat (grad of BN weight) */
     float* dbeta;          /* BN_BWD_APPLY: optional [C] <- sum dz      (grad of BN bias) */
     fpd_bn_t bn;
@@ -299,7 +310,7 @@ typedef struct {
 /* Running-statistics update of train-mode BNs after a forward (torch: momentum 0.1, unbiased
  * variance; hourglass.py:10).  One launch for a table. */
 typedef struct {
-    const double* stats;   /* [R][2][C] */
+    const fpd_stat_t* stats; /* statistics buffer over C */
     float* running_mean; float* running_var; int64_t* num_batches_tracked;
     double count; float momentum; int32_t C;
 } fpd_bnupd_entry_t;

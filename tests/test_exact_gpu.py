@@ -42,9 +42,10 @@ def sparse_weights(gen, K, R, C, per_out=2):
 def exact_equal(bench, b, label):
     b = b.buf if hasattr(b, 'buf') else b
     c = bench.cpu.view(b).double()
-    g = bench.gpu.view(b).cpu().double()
-    if b.arena == 'stats':
-        c, g = c.sum(0), g.sum(0)
+    if b.arena == 'stats':                  # device: exact integer limbs (include/fpd_amd.h fpd_stat_t), decoded per replica
+        c, g = c.sum(0), bench.gpu.stats_read(b).cpu().sum(0)
+    else:
+        g = bench.gpu.view(b).cpu().double()
     bad = c != g
     assert not bad.any(), '%s: %d/%d elements differ (max |diff| %.3e), first at %s' % (
         label, int(bad.sum()), bad.numel(), float((c - g).abs().max()), [int(i) for i in torch.nonzero(bad)[0]])

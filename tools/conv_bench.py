@@ -71,7 +71,9 @@ def main():
             if bnm == 'train':
                 bn.stats = G.Buf('stats', 0, (G.STATS_REPLICAS, 2, C))
                 xv = A.view(x.buf).double()
-                A.view(bn.stats)[0].copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
+                st0 = torch.zeros(bn.stats.shape, dtype=torch.float64)
+                st0[0] = torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]).cpu()
+                A.stats_write(bn.stats, st0)
         low = E.Lowering(A, dtype)
         if args.wgrad:
             op = G.Op('wgrad', x=x, dy=y, dw=G.Buf('grad', 0, (K, Rr, Rr, C)), dbias=G.Buf('grad', K * Rr * Rr * C, (K,)), bn=bn,

@@ -17,7 +17,7 @@ x = G.Act((N, H, W, C)); x.buf = G.Buf('act', 0, x.shape)
 dy = G.Act((N, H, W, K)); dy.buf = G.Buf('act', M * C, dy.shape)
 bn = G.BN('bn', 'train', C, G.Buf('param', 0, (C,)), G.Buf('param', C, (C,)), G.Buf('rstat', 0, (C,)), G.Buf('rstat', C, (C,)), G.Buf('nbt', 0, ()))
 bn.count = M; bn.stats = G.Buf('stats', 0, (G.STATS_REPLICAS, 2, C))
-xv = A.view(x.buf).double(); A.view(bn.stats)[0].copy_(torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]))
+xv = A.view(x.buf).double(); st0 = torch.zeros(bn.stats.shape, dtype=torch.float64); st0[0] = torch.stack([xv.sum((0, 1, 2)), (xv * xv).sum((0, 1, 2))]).cpu(); A.stats_write(bn.stats, st0)
 op = G.Op('wgrad', x=x, dy=dy, dw=G.Buf('grad', 0, (K, Rr, Rr, C)), dbias=G.Buf('grad', K * Rr * Rr * C, (K,)), bn=bn, dims=(N, H, W, C, K, Rr, Rr, 1, pad, H, W))
 plan = R.Plan(); plan.add(*E.Lowering(A, dtype).op(op))
 res = []

@@ -1,26 +1,54 @@
 #!/usr/bin/env python
 """Aggregates the rocprofv3 output of tools/profile.sh into the small tables kept under profiles/ (rNN = the prefix argument):
   rNN_kernel_stats.csv      rocprofv3's own --stats table
-  rNN_per_shape.csv         per (kernel, grid): calls per step, average us, ms per step (the --stats averages mix shapes)
-  rNN_hbm_traffic.csv       per (kernel, grid): FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes), HBM bytes per launch
-                            = (2 x FETCH + WRITE) x 1024 (gfx950: FETCH_SIZE counts wide coalesced reads at 1/2, MI355X_MICROARCH.md),
-                            average duration from the un-counted trace, GB/s and the fraction of the 8 TB/s HBM3E peak
+  rNN_per_shape.csv         per (kernel, grid, SHAPE): calls per step, average us, ms per step.  The shape (plan op kind, N/H/W/C/K/R,
+                            forward / data gradient, fused extras) is not in the trace; it comes from the library's launch log of the
+                            same process (FPD_LAUNCH_LOG, include: csrc/common.h FPD_LAUNCH): one line per kernel launch in host
+                            order, matched 1:1 with the trace rows of the library's kernels sorted by Dispatch_Id (the same host
+                            order) and verified by kernel name.  So e.g. the fused Bottleneck's 64x64 launches and its 32x32
+                            launches (same persistent grid) are separate rows, and every figure bench.py quotes for a (kernel, shape)
+                            can be recomputed from this file.
+  rNN_hbm_traffic.csv       per (kernel, grid, shape): FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes, each with its own
+                            launch log), HBM bytes per launch = (2 x FETCH + WRITE) x 1024 (gfx950: FETCH_SIZE counts wide coalesced
+                            reads at 1/2, MI355X_MICROARCH.md), average duration from the un-counted trace, GB/s and the fraction
+                            of the 8 TB/s HBM3E peak
   rNN_pmc_bneck64.json      the same for the dominant kernel from its micro-benchmark (what bench.py's roofline.traffic quotes)"""
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
 out = sys.argv[1]
-PFX = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+PFX = sys.argv[2] if len(sys.argv) > 2 else 'r04'
+SUB = sys.argv[3] if len(sys.argv) > 3 else ''      # 'hrnet_': the passes over `bench.py --config hrnet` (directories hrnet_stats, hrnet_step_*)
 STEPS = None      # set from the trace: one adam_kernel launch per student step (eager + warm-up + timed + the host-enqueue probe step)
 
 
 def short(n):
     return n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:60]
+
+
+def base_name(expr):
+    """'(conv_pp_kernel<R, C, KH, BWD, WG>)' / 'adam_kernel' -> 'conv_pp_kernel' (what the trace's kernel name must contain)"""
+    return re.sub(r'[(<].*', '', expr.strip().lstrip('(')).strip()
+
+
+def load_log(sub):
+    """[(kernel base name, grid blocks, block threads, op index, shape tag)] in host order, or None."""
+    path = os.path.join(out, sub, 'launch.log')
+    if not os.path.exists(path):
+        return None
+    rows = []
+    for line in open(path):
+        f = line.rstrip('\n').split('\t')
+        if len(f) < 4:
+            continue
+        rows.append((base_name(f[0]), int(f[1]), int(f[2]), f[3], f[4] if len(f) > 4 else ''))
+    return rows
 
 
 def trace(sub):
@@ -30,11 +58,33 @@ def trace(sub):
     return rows
 
 
+def shapes_by_dispatch(sub, rows):
+    """Dispatch_Id -> shape tag for the library's kernels of trace `rows`, by 1:1 alignment with the launch log."""
+    log = load_log(sub)
+    if not log:
+        print('%s: no launch log -- rows are keyed on (kernel, grid) only' % sub)
+        return {}
+    names = set(l[0] for l in log)
+    ours = [r for r in sorted(rows, key=lambda r: int(r['Dispatch_Id'])) if any(n in r['Kernel_Name'] for n in names)]
+    tags, bad = {}, 0
+    if len(ours) != len(log):
+        print('%s: %d trace rows of library kernels vs %d logged launches -- aligning the common prefix' % (sub, len(ours), len(log)))
+    for r, l in zip(ours, log):
+        if l[0] not in r['Kernel_Name']:
+            bad += 1
+            continue
+        tags[r['Dispatch_Id']] = l[4]
+    print('%s: %d launches keyed on their shape, %d name mismatches' % (sub, len(tags), bad))
+    return tags
+
+
 # 1. stats
-for f in glob.glob('%s/stats/**/*kernel_stats.csv' % out, recursive=True):
-    shutil.copy(f, os.path.join(out, PFX + '_kernel_stats.csv'))
+for f in glob.glob('%s/%sstats/**/*kernel_stats.csv' % (out, SUB), recursive=True):
+    shutil.copy(f, os.path.join(out, PFX + '_' + SUB + 'kernel_stats.csv'))
 dur = collections.defaultdict(list)
-rows_stats = sorted(trace('stats'), key=lambda r: int(r['Start_Timestamp']))
+all_rows = trace(SUB + 'stats')
+tags = shapes_by_dispatch(SUB + 'stats', all_rows)
+rows_stats = sorted(all_rows, key=lambda r: int(r['Start_Timestamp']))
 adams = [i for i, r in enumerate(rows_stats) if 'adam_kernel' in r['Kernel_Name']]
 STEPS = len(adams)
 # bench.py re-times single recorded ops live after its last step (roofline.avg_us, conv_classes): not part of a step
@@ -44,39 +94,51 @@ print('%d steps in the trace; %d kernel records behind the last step (live re-ti
 for r in rows_stats:
     grid = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
     wg = int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
-    dur[(short(r['Kernel_Name']), str(grid), str(wg))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-with open(os.path.join(out, PFX + '_per_shape.csv'), 'w', newline='') as f:
+    dur[(short(r['Kernel_Name']), str(grid), str(wg), tags.get(r['Dispatch_Id'], ''))].append(
+        (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+with open(os.path.join(out, PFX + '_' + SUB + 'per_shape.csv'), 'w', newline='') as f:
     w = csv.writer(f)
-    w.writerow(['kernel', 'grid_threads', 'workgroup', 'calls_per_step', 'avg_us', 'ms_per_step'])
+    w.writerow(['kernel', 'grid_threads', 'workgroup', 'shape', 'calls_per_step', 'avg_us', 'min_us', 'ms_per_step'])
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        w.writerow([k[0], k[1], k[2], round(len(v) / STEPS, 1), round(sum(v) / len(v), 2), round(sum(v) / STEPS / 1e3, 3)])
+        w.writerow([k[0], k[1], k[2], k[3], round(len(v) / STEPS, 1), round(sum(v) / len(v), 2), round(min(v), 2), round(sum(v) / STEPS / 1e3, 3)])
 total = sum(sum(v) for v in dur.values()) / STEPS / 1e3
 print('serialised kernel time per step: %.2f ms' % total)
+
 
 # 2. counters
 def counters(sub, name):
     agg = collections.defaultdict(list)
-    for f in glob.glob('%s/%s/**/*counter_collection.csv' % (out, sub), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == name:
-                agg[(short(r['Kernel_Name']), r['Grid_Size'])].append(float(r['Counter_Value']))
+    files = glob.glob('%s/%s/**/*counter_collection.csv' % (out, sub), recursive=True)
+    rows = [r for f in files for r in csv.DictReader(open(f))]
+    # one row per (dispatch, counter): the alignment wants every dispatch once
+    seen, uniq = set(), []
+    for r in rows:
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            uniq.append(r)
+    t = shapes_by_dispatch(sub, uniq)
+    for r in rows:
+        if r['Counter_Name'] == name:
+            agg[(short(r['Kernel_Name']), r['Grid_Size'], t.get(r['Dispatch_Id'], ''))].append(float(r['Counter_Value']))
     return agg
 
 
-fe, wr = counters('step_FETCH_SIZE', 'FETCH_SIZE'), counters('step_WRITE_SIZE', 'WRITE_SIZE')
-with open(os.path.join(out, PFX + '_hbm_traffic.csv'), 'w', newline='') as f:
+fe, wr = counters(SUB + 'step_FETCH_SIZE', 'FETCH_SIZE'), counters(SUB + 'step_WRITE_SIZE', 'WRITE_SIZE')
+with open(os.path.join(out, PFX + '_' + SUB + 'hbm_traffic.csv'), 'w', newline='') as f:
     w = csv.writer(f)
-    w.writerow(['kernel', 'grid_threads', 'launches_counted', 'FETCH_KB', 'WRITE_KB', 'hbm_MB_per_launch', 'avg_us', 'GB_per_s', 'frac_of_8TBs'])
+    w.writerow(['kernel', 'grid_threads', 'shape', 'launches_counted', 'FETCH_KB', 'WRITE_KB', 'hbm_MB_per_launch', 'avg_us', 'GB_per_s', 'frac_of_8TBs'])
     for k in sorted(set(fe) | set(wr), key=lambda k: -sum(fe.get(k, [0])) - sum(wr.get(k, [0]))):
         a, b = fe.get(k, []), wr.get(k, [])
         if not a or not b:
             continue
         fkb, wkb = sum(a) / len(a), sum(b) / len(b)
         byt = (2 * fkb + wkb) * 1024
-        us = [v for kk, v in dur.items() if kk[0] == k[0] and kk[1] == k[1]]
+        us = [v for kk, v in dur.items() if kk[0] == k[0] and kk[1] == k[1] and kk[3] == k[2]]
         us = sum(us[0]) / len(us[0]) if us else 0.0
         gbs = byt / us / 1e3 if us else 0.0
-        w.writerow([k[0], k[1], len(a), round(fkb, 1), round(wkb, 1), round(byt / 1e6, 2), round(us, 2), round(gbs, 1), round(gbs / 8000.0, 3)])
+        w.writerow([k[0], k[1], k[2], len(a), round(fkb, 1), round(wkb, 1), round(byt / 1e6, 2), round(us, 2), round(gbs, 1), round(gbs / 8000.0, 3)])
+if SUB:
+    sys.exit(0)
 res = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     vals = [v for k, vs in counters('bneck_' + c, c).items() if 'bneck_eval_kernel' in k[0] for v in vs]
