@@ -49,8 +49,8 @@ template <int P>
 __device__ __forceinline__ void bneck_fold_tables(const fpd_bneck_t& a, float* out, int tid, int nthreads) {
     constexpr int C = 2 * P;
     for (int c = tid; c < C; c += nthreads) {
-        float sc, sh, mu, is;
-        bn_coef(a.bn1, c, C, 1.0, sc, sh, mu, is);
+        float sc, sh;
+        bn_coef_eval(a.bn1, c, sc, sh);
         out[c] = sc;
         out[C + c] = sh;
         out[2 * C + 4 * P + c] = a.b3 ? a.b3[c] : 0.f;
@@ -58,8 +58,8 @@ __device__ __forceinline__ void bneck_fold_tables(const fpd_bneck_t& a, float* o
     for (int c = tid; c < 2 * P; c += nthreads) {
         const bool second = c >= P;
         const int cc = second ? c - P : c;
-        float sc, sh, mu, is;
-        bn_coef(second ? a.bn3 : a.bn2, cc, P, 1.0, sc, sh, mu, is);
+        float sc, sh;
+        bn_coef_eval(second ? a.bn3 : a.bn2, cc, sc, sh);
         const float* bias = second ? a.b2 : a.b1;
         out[2 * C + (second ? 2 * P : 0) + cc] = sc;
         out[2 * C + (second ? 2 * P : 0) + P + cc] = fmaf(sc, bias ? bias[cc] : 0.f, sh);

@@ -180,6 +180,8 @@ __device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnR
     for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { r.s1.hi[q] = r.s1.lo[q] = r.s2.hi[q] = r.s2.lo[q] = 0; }
     r.g = 1.f; r.b = 0.f; r.rm = 0.f; r.rv = 1.f;
     if (bn.mode == FPD_BN_NONE) return;
+    r.g = bn.gamma[c];
+    r.b = bn.beta[c];
     if (bn.mode == FPD_BN_TRAIN) {
         stat_request(bn.stats, C, 0, c, r.s1);
         stat_request(bn.stats, C, 1, c, r.s2);
@@ -187,8 +189,6 @@ __device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnR
         r.rm = bn.running_mean[c];
         r.rv = bn.running_var[c];
     }
-    r.g = bn.gamma[c];
-    r.b = bn.beta[c];
 }
 __device__ __forceinline__ void bn_resolve(const BnRaw& r, double count, float& scale, float& shift, float& mean, float& invstd) {
     double m, var;
@@ -212,6 +212,17 @@ __device__ __forceinline__ void bn_coef(const fpd_bn_t& bn, int c, int C, double
     BnRaw r;
     bn_request(bn, c, C, r);
     bn_resolve(r, count, scale, shift, mean, invstd);
+}
+
+// The same for a FROZEN network's BatchNorm (running estimates only; the fused teacher kernels, whose API admits nothing else).
+// Kept free of the mode dispatch on purpose: inlined into bneck_eval_kernel the three-way dispatch of bn_request() was
+// miscompiled by hipcc 7.2 (the gamma / beta address registers were left undefined on the EVAL path: memory fault).
+__device__ __forceinline__ void bn_coef_eval(const fpd_bn_t& bn, int c, float& scale, float& shift) {
+    const double m = (double)bn.running_mean[c], var = (double)bn.running_var[c];
+    const double is = 1.0 / sqrt(var + (double)bn.eps);
+    const double g = (double)bn.gamma[c];
+    scale = (float)(g * is);
+    shift = (float)((double)bn.beta[c] - m * g * is);
 }
 
 // Fill LDS scale/shift tables for all C channels (call from every thread, then __syncthreads()).

@@ -30,8 +30,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int C>
 __device__ __forceinline__ void head_tables(const fpd_head_t& a, float* out, int tid, int nthreads) {
     for (int c = tid; c < C; c += nthreads) {
-        float sc, sh, mu, is;
-        bn_coef(a.bn, c, C, 1.0, sc, sh, mu, is);
+        float sc, sh;
+        bn_coef_eval(a.bn, c, sc, sh);
         out[c] = sc;
         out[C + c] = fmaf(sc, a.b_fc ? a.b_fc[c] : 0.f, sh);
         out[2 * C + 32 + c] = (a.b_fc2 ? a.b_fc2[c] : 0.f) + (a.b_score2 ? a.b_score2[c] : 0.f);

@@ -69,6 +69,75 @@ __global__ __launch_bounds__(256) void loss_kernel(const fpd_loss_t a) {
     }
 }
 
+// Vectorised variant (J a multiple of the 16-byte vector: 8 joints in bf16, 4 in fp32): block = 128 consecutive pixels of one
+// image; a thread owns ONE 16-byte vector of joints of one pixel for all S stacks -- one vector load per map, one vector store
+// per gradient (the element-per-thread kernel above moves 2-byte words: 65 us for the 2 M elements of the benchmark, on the
+// student's critical chain).  Same arithmetic per element, same per-block sums (fixed order), same grid-aligned loss terms.
+template <typename T>
+__global__ __launch_bounds__(256) void loss_vec_kernel(const fpd_loss_t a) {
+    constexpr int VEC = DT<T>::VEC, PT = 128;
+    __shared__ float s_tg[PT * 33];       // [pixel][joint], J <= 32, padded rows
+    __shared__ double s_acc[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int J = a.J, HW = a.H * a.W;
+    const int tiles_per_img = (HW + PT - 1) / PT;
+    const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * PT;
+    const int LDJ = J + 1;
+    if (a.target_nchw) {
+        for (int i = tid; i < J * PT; i += 256) {
+            const int j = i / PT, p = i - j * PT;
+            s_tg[p * LDJ + j] = (p0 + p < HW) ? a.target[((size_t)b * J + j) * HW + p0 + p] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < J * PT; i += 256) {
+            const int p = i / J, j = i - p * J;
+            s_tg[p * LDJ + j] = (p0 + p < HW) ? a.target[((size_t)b * HW + p0 + p) * J + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    const double cnt = (double)a.B * J * HW;
+    const float gs = a.grad_scale / (float)cnt;
+    const T* tch = reinterpret_cast<const T*>(a.teacher);
+    const int VPP = J / VEC;                     // vectors per pixel
+    float pose = 0.f, kd = 0.f;
+    for (int v = tid; v < PT * VPP; v += 256) {
+        const int p = v / VPP, j0 = (v - p * VPP) * VEC;
+        if (p0 + p >= HW) continue;
+        const size_t off = ((size_t)b * HW + p0 + p) * J + j0;
+        float w2[VEC], w2k[VEC], g[VEC], t[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float wgt = a.weight[b * J + j0 + e];
+            const float wk = a.weight_kd ? a.weight_kd[b * J + j0 + e] : wgt;
+            w2[e] = wgt * wgt; w2k[e] = wk * wk;
+            g[e] = s_tg[p * LDJ + j0 + e];
+        }
+        DT<T>::unpack(*reinterpret_cast<const uint4*>(tch + off), t);
+        for (int s = 0; s < a.S; ++s) {
+            float pv[VEC], d[VEC];
+            DT<T>::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.out[s]) + off), pv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float dg = pv[e] - g[e], dt = pv[e] - t[e];
+                pose += w2[e] * dg * dg;
+                kd += w2k[e] * dt * dt;
+                d[e] = gs * ((1.f - a.alpha) * w2[e] * dg + a.alpha * w2k[e] * dt);
+            }
+            if (a.dout[s] != nullptr) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.dout[s]) + off) = DT<T>::pack(d);
+        }
+    }
+    const double dp = wave_sum_d((double)pose), dk = wave_sum_d((double)kd);
+    if (lane == 0) { s_acc[0][wave] = dp; s_acc[1][wave] = dk; }
+    __syncthreads();
+    if (tid == 0) {
+        const double sc = 0.5 / cnt, q = 17592186044416.0;     // 2^44 (see loss_kernel)
+        const double vp = sc * (s_acc[0][0] + s_acc[0][1] + s_acc[0][2] + s_acc[0][3]);
+        const double vk = sc * (s_acc[1][0] + s_acc[1][1] + s_acc[1][2] + s_acc[1][3]);
+        atomicAdd(a.losses + 0, rint(vp * q) / q);
+        atomicAdd(a.losses + 1, rint(vk * q) / q);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const fpd_adam_t a) {
     float bc1 = a.bias_corr1, bc2 = a.bias_corr2, lr = a.lr;
     if (a.step_dev != nullptr) {
@@ -155,6 +224,17 @@ inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64
 
 int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st) {
     if (a.J > 32 || a.S > FPD_MAX_STACKS || a.S < 1) return fpd_fail(-3, "loss: J=%d (<=32), S=%d (1..%d)", a.J, a.S, FPD_MAX_STACKS);
+    const int vec = a.dtype == FPD_BF16 ? 8 : 4;
+    bool aligned = a.J % vec == 0 && ((uintptr_t)a.teacher & 15) == 0;
+    for (int s = 0; s < a.S; ++s) aligned = aligned && ((uintptr_t)a.out[s] & 15) == 0 && ((uintptr_t)a.dout[s] & 15) == 0;
+    if (aligned) {                               // 16-byte vectors of joints (the benchmark's J = 16)
+        const int vt = a.B * cdiv(a.H * a.W, 128);
+        if (a.dtype == FPD_BF16)
+            FPD_LAUNCH((loss_vec_kernel<bf16_t>), dim3(vt), dim3(256), 0, st, a);
+        else
+            FPD_LAUNCH((loss_vec_kernel<float>), dim3(vt), dim3(256), 0, st, a);
+        return 0;
+    }
     const int tiles = a.B * cdiv(a.H * a.W, 64);
     if (a.dtype == FPD_BF16)
         FPD_LAUNCH((loss_kernel<bf16_t>), dim3(tiles), dim3(256), 0, st, a);

@@ -104,7 +104,7 @@ def test_hourglass_two_shards_on_one_gpu_match_the_mean_of_shard_gradients():
     ours = _flat_model_grads(reps[0].model)
     # oracle: per-shard gradients of the per-shard mean loss, averaged over the shards (fp32 and fp64)
     keys = reps[0].model.table.trainable_keys()
-    mean32, mean64, losses32 = 0, 0, []
+    mean32, mean64, losses32, losses64 = 0, 0, [], []
     for r in range(2):
         s_sd, t_sd = _cases.state_dicts(name)
         g32 = fpd_ref.fpd_step(s_sd, t_sd, c['s'][1], c['t'][1], x[r:r + 1], tg[r:r + 1], tw[r:r + 1], 0.5)
@@ -115,9 +115,13 @@ def test_hourglass_two_shards_on_one_gpu_match_the_mean_of_shard_gradients():
         t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
         g64 = fpd_ref.fpd_step(s64, t64, c['s'][1], c['t'][1], x[r:r + 1].double(), tg[r:r + 1].double(), tw[r:r + 1].double(), 0.5)
         mean64 = mean64 + torch.cat([g64['grads'][k].reshape(-1) for k in keys]) / 2
+        losses64.append((float(g64['pose']), float(g64['kd'])))
     for r, rep in enumerate(reps):                         # each rank reports the loss of ITS shard (local mean)
-        pose, kd, _ = rep.step.losses()
-        assert abs(pose - losses32[r][0]) < 2e-5 and abs(kd - losses32[r][1]) < 2e-5, (r, pose, kd, losses32[r])
+        # one sample per shard: the BN statistics of a shard come from 1 image, and the fp32 reference itself is 1e-4 away
+        # from fp64 on these losses -- same two-sided criterion as everywhere: never less accurate than 1.5x the reference
+        for ours, r32, r64 in zip(rep.step.losses()[:2], losses32[r], losses64[r]):
+            assert abs(ours - r64) <= max(2e-5, 1.5 * abs(r32 - r64)), (r, ours, r32, r64)
+            assert abs(ours - r32) <= 1e-4 + abs(r32 - r64), (r, ours, r32, r64)
     _cases.assert_parity(ours.numpy(), mean32.numpy(), mean64.numpy(), 'all-reduced gradient of two shards', floor=2e-6, atol=1e-5)
     # Adam on both replicas: identical parameters, one update of at most lr per element away from the oracle's
     p_before = reps[0].model.device_state().A.tensor('param').clone()
@@ -157,16 +161,22 @@ def test_hrnet_two_shards_bucketed_reduction_equals_single_reduction():
     s_sd = fpd_ref.synth_state_dict(hrnet_ref.hrnet_keys(ex_s, c['joints']), 1)
     t_sd = fpd_ref.synth_state_dict(hrnet_ref.hrnet_keys(ex_t, c['joints']), 2)
     names = [k for k in s_sd if s_sd[k].is_floating_point() and 'running' not in k]
-    mean64 = 0
+    fwd = dict(student_forward=lambda sd, xx, train: [hrnet_ref.hrnet_forward(sd, ex_s, xx, train=train)],
+               teacher_forward=lambda sd, xx, train: [hrnet_ref.hrnet_forward(sd, ex_t, xx, train=train)])
+    mean64, mean32 = 0, 0
     for r in range(2):
         s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in copy.deepcopy(s_sd).items()}
         t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
-        g = fpd_ref.fpd_step(s64, t64, 1, 1, x[r:r + 1].double(), tg[r:r + 1].double(), tw[r:r + 1].double(), c['alpha'],
-                             student_forward=lambda sd, xx, train: [hrnet_ref.hrnet_forward(sd, ex_s, xx, train=train)],
-                             teacher_forward=lambda sd, xx, train: [hrnet_ref.hrnet_forward(sd, ex_t, xx, train=train)])
+        g = fpd_ref.fpd_step(s64, t64, 1, 1, x[r:r + 1].double(), tg[r:r + 1].double(), tw[r:r + 1].double(), c['alpha'], **fwd)
         mean64 = mean64 + torch.cat([g['grads'][k].reshape(-1) for k in names]) / 2
+        g = fpd_ref.fpd_step(copy.deepcopy(s_sd), copy.deepcopy(t_sd), 1, 1, x[r:r + 1], tg[r:r + 1], tw[r:r + 1], c['alpha'], **fwd)
+        mean32 = mean32 + torch.cat([g['grads'][k].reshape(-1) for k in names]).double() / 2
     rel = float((ours - mean64).norm() / mean64.norm())
-    assert rel < 5e-3, rel                                  # the bound tests/test_hrnet_gpu.py holds the one-rank step to
+    rel32 = float((mean32 - mean64).norm() / mean64.norm())
+    # one sample per shard on 3x4 ... 24x32 maps: BN statistics over as few as 12 pixels amplify fp32 rounding (the one-rank
+    # step at B = 2 is held to 5e-3, tests/test_hrnet_gpu.py); the reference's own fp32 arithmetic is the yardstick
+    print('hrnet two shards: gradient rel-L2 vs fp64 %.2e (reference fp32: %.2e)' % (rel, rel32))
+    assert rel <= max(5e-3, 1.5 * rel32), (rel, rel32)
     for rep in reps:
         rep.step.flush()
     torch.cuda.synchronize()
