@@ -681,6 +681,11 @@ static int pp_occ_cap() {    // FPD_CONV_PP_OCC: resident blocks per CU the grid
     if (v < 0) { const char* e = getenv("FPD_CONV_PP_OCC"); v = e ? atoi(e) : 2; }
     return v < 1 ? 1 : v;
 }
+static int pp_blocks_bwd() { // FPD_CONV_PP_BLOCKS_BWD: persistent blocks of the data-gradient kernels (one per CU; default = FPD_CONV_PP_BLOCKS)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS_BWD"); v = e ? atoi(e) : 0; }
+    return v > 0 ? v : pp_blocks();
+}
 static int pp_fuse_wgrad() { // FPD_CONV_PP_WGRAD: 0 = never fuse the weight gradient into the data-gradient launch
     static int v = -1;
     if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD"); v = e ? atoi(e) : 1; }
@@ -750,7 +755,7 @@ static bool pp_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, PPPl
     const int occ = bwd ? 1 : std::max(1, std::min(pp_occ_cap(), (int)(PP_LDS_MAX / pl.lds)));
     pl.ks = cdiv(a.K, 64);                                 // channel slabs of <= 64 (K = 128: two blocks per tile range)
     // tile ranges: ks blocks per range, every block should own at least two tiles
-    int ranges = std::max(1, std::min(pp_blocks() * occ / pl.ks, total / 2));
+    int ranges = std::max(1, std::min((bwd ? pp_blocks_bwd() : pp_blocks()) * occ / pl.ks, total / 2));
     if (b != nullptr) {
         if (ranges < 2) return false;
         pl.gb.nblk = std::max(1, std::min(ranges - 1, (int)((long long)ranges * pl.gb.ntiles / total)));

@@ -437,6 +437,14 @@ static bool tile_domain(const fpd_conv_t& a) {
 }
 // the halo of one channel chunk must fit the 8 staging vectors a thread holds
 static bool halo_fits(const fpd_conv_t& a, int vpr) { return (tile_rows(a.W) + a.R - 1) * a.W * vpr <= 2048; }
+// channel chunk of a single bf16 launch: the widest of 64 / 32 / 16 that divides C and whose halo fits (0: none).  A 3x3
+// convolution on 128-wide rows does not fit 64-channel chunks (3 rows x 128 pixels x 8 vectors): it runs on 32-channel
+// chunks instead of falling through to the generic kernel (the frozen teacher's 3x3 64->64 at 128x128: 165 us there)
+static int tile_bk_bf16(const fpd_conv_t& a) {
+    for (int bk = 64; bk >= 16; bk >>= 1)
+        if (a.C % bk == 0 && halo_fits(a, bk / 8)) return bk;
+    return 0;
+}
 
 template <typename T, int TN, int BK, bool ALLW>
 int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
@@ -488,7 +496,7 @@ int launch_pair_tn(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
 // the LDS never runs out.
 static bool tile_fold_shape(const fpd_conv_t& a) {
     if (a.epi != FPD_EPI_BNRELU_BWD || a.bn.mode != FPD_BN_NONE || !tile_domain(a) || a.C > 128 || a.K > 128) return false;
-    if (a.dtype == FPD_BF16) return halo_fits(a, ((a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16)) / 8);
+    if (a.dtype == FPD_BF16) return tile_bk_bf16(a) != 0;
     return halo_fits(a, ((a.C % 32 == 0) ? 32 : 16) / 4);
 }
 int fpd_conv_tile_fold_ok(const fpd_conv_t& a) { return (tile_fold_shape(a) && tile_tn(a.K, tiles_of(a)) <= 2) ? 1 : 0; }
@@ -522,8 +530,8 @@ int fpd_conv_tile_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStrea
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st) {
     if (!tile_domain(a)) return 1;
     if (a.dtype == FPD_BF16) {
-        const int bk = (a.C % 64 == 0) ? 64 : ((a.C % 32 == 0) ? 32 : 16);
-        if (!halo_fits(a, bk / 8)) return 1;
+        const int bk = tile_bk_bf16(a);
+        if (bk == 0) return 1;
         if (bk == 64) return launch_tile_tn<bf16_t, 64>(a, st);
         if (bk == 32) return launch_tile_tn<bf16_t, 32>(a, st);
         return launch_tile_tn<bf16_t, 16>(a, st);

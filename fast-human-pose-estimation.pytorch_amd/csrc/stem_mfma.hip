@@ -271,12 +271,12 @@ int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     const size_t tile = (size_t)(128 + 32 * TN) * LDA * sizeof(bf16_t);
     const size_t lds = std::max(tile, (size_t)128 * (32 * TN + 4) * sizeof(float)) + patch_bytes(logQ);
     const int tiles = a.N * a.P * a.Q / 128;
-    static bool cfg1 = false, cfg2 = false;
+    static LdsAttr cfg1, cfg2;          // per device, set once (thread-safe: common.h)
     if (TN == 1) {
-        if (!cfg1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg1 = true; }
+        if (int rc_ = cfg1.ensure(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<1>), lds)) return rc_;
         FPD_LAUNCH((stem_fwd_mfma_kernel<1>), dim3(tiles), dim3(256), lds, st, a, logQ);
     } else {
-        if (!cfg2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg2 = true; }
+        if (int rc_ = cfg2.ensure(reinterpret_cast<const void*>(&stem_fwd_mfma_kernel<2>), lds)) return rc_;
         FPD_LAUNCH((stem_fwd_mfma_kernel<2>), dim3(tiles), dim3(256), lds, st, a, logQ);
     }
     return 0;
@@ -293,8 +293,8 @@ int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     if (!stem_mfma_ok(a, logQ)) return 1;
     const size_t lds = (size_t)128 * LDA * sizeof(bf16_t) + (size_t)128 * 72 * sizeof(bf16_t) + patch_bytes(logQ);
     const int tiles = a.N * a.P * a.Q / 128;
-    static bool cfg = false;
-    if (!cfg) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); cfg = true; }
+    static LdsAttr cfg;                 // per device, set once (thread-safe: common.h)
+    if (int rc_ = cfg.ensure(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel), lds)) return rc_;
     FPD_LAUNCH(stem_wgrad_mfma_kernel, dim3(a.partial != nullptr ? std::min(tiles, 512) : 1), dim3(256), lds, st, a, logQ, tiles);
     return 0;
 }

@@ -26,6 +26,13 @@ WGRAD_LANES = 1
 LANE_LEVELS = 0
 FOLD_APPLY = os.environ.get('FPD_FOLD_APPLY', '1') != '0'     # BN-backward applies evaluated by the consuming data gradient where the library offers it
 WREDUCE_PER_BATCH = os.environ.get('FPD_WREDUCE_PER_BATCH', '0') == '1'   # slab reduction per weight-gradient batch instead of once per gradient bucket (measured equal: 10.67 vs 10.67 ms, 22 more launches)
+# FPD_WREDUCE_MODE: where the slabs of a gradient bucket are summed on the weight-gradient lane.
+#   bucket  one reduction at the end of the bucket (round 3): the LAST bucket's reduction (130 us over 116 tensors) sits between the
+#           last weight gradient and Adam, fully exposed (profiles/r04a trace: the chain ends 435 us before Adam starts)
+#   batch   one behind every batch (= FPD_WREDUCE_PER_BATCH=1)
+#   lag     one IN FRONT of every batch, covering the batches before it: the lane sums finished slabs while it waits for the
+#           next batch's operands anyway, and what remains behind the last weight gradient covers the last batch only
+WREDUCE_MODE = os.environ.get('FPD_WREDUCE_MODE', 'batch' if WREDUCE_PER_BATCH else 'lag')
 WGRAD_BATCH = 8     # re-swept in round 2 on one box: 1/2/4/8/12/16/24/32 -> 11.92/11.83/11.69/11.67/11.81/11.83/11.90/11.99 ms (the lane tail before Adam)
 
 
@@ -697,8 +704,7 @@ class HourglassGraph:
                 dy = op.y.grad
                 sw = Op('stem_wgrad', image=self.image, dy=dy, dw=self.p.grad('conv1.weight'),
                         dbias=self.p.grad('conv1.bias'), dims=op.dims, lane=1 + self.depth)
-                self.bwd.append(sw)
-                self._wg_bucket.append(sw)       # its slabs are summed by the bucket's 'wreduce' like every other weight gradient
+                self._wg_pending.append(sw)      # issued with the last batch; its slabs are summed like every other weight gradient's
             elif op.kind == 'ew':
                 self._ew_backward(op)
             elif op.kind == 'affsum':
@@ -733,16 +739,21 @@ class HourglassGraph:
         that the batch's first kernel carries the one cross-lane wait that covers the whole batch.  The slabs of a batch
         are summed right behind it (WREDUCE_PER_BATCH; always at the end of a bucket): the reduction that remains in
         front of Adam after the last data gradient then covers the last batch only, not the whole last bucket."""
+        def emit_reduce():
+            if self._wg_bucket:
+                bufs = [x for w in self._wg_bucket for x in (w.dw, w.dbias) if x is not None]
+                self.bwd.append(Op('wreduce', bucket=self._cur_bucket if b is None else b, wgrads=list(self._wg_bucket), bufs=bufs,
+                                   lane=1 + self.depth))
+                self._wg_bucket = []
+        if WREDUCE_MODE == 'lag' and self._wg_pending:
+            emit_reduce()                        # the batches issued before this one: their slabs are complete (or about to be)
         for w in reversed(self._wg_pending):
             self.bwd.append(w)
-            if w.kind == 'wgrad':
+            if w.kind in ('wgrad', 'stem_wgrad'):
                 self._wg_bucket.append(w)
         self._wg_pending = []
-        if (WREDUCE_PER_BATCH if reduce is None else reduce) and self._wg_bucket:
-            bufs = [x for w in self._wg_bucket for x in (w.dw, w.dbias) if x is not None]
-            self.bwd.append(Op('wreduce', bucket=self._cur_bucket if b is None else b, wgrads=list(self._wg_bucket), bufs=bufs,
-                               lane=1 + self.depth))
-            self._wg_bucket = []
+        if (WREDUCE_MODE == 'batch') if reduce is None else reduce:
+            emit_reduce()
 
     def _emit_dgrad(self, op):
         c = self._pair_op

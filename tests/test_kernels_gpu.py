@@ -161,6 +161,7 @@ CONV_CASES = [
     (2, 16, 16, 3, 64, 3, 1, None, False, True),        # conv_smallc: HRNet's first stem conv (C = 3), statistics for bn1
     (2, 16, 12, 17, 32, 1, 0, None, False, False),      # conv_smallc: data gradient of the J = 17 final layer
     (1, 9, 7, 5, 8, 1, 0, None, True, False),           # conv_smallc: J = 5 test networks, ragged M, accumulate source
+    (1, 6, 128, 64, 64, 3, 1, 'eval', False, False),    # teacher layer1 3x3 on 128-wide rows: 32-channel chunks (the 64-channel halo does not fit)
 ]
 
 
