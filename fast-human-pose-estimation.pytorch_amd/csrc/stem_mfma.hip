@@ -158,10 +158,13 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const fpd_stem_t a, 
     conv_epilogue_vec<bf16_t, TN>(c, acc, m0, 0, M, nullptr, reinterpret_cast<float*>(sA), reinterpret_cast<double*>(sA));
 }
 
-// grid-stride over pixel tiles; dW[k][tap] accumulated in registers, one flush per block (to its slab)
+// grid-stride over pixel tiles; dW[k][tap] accumulated in registers, one flush per block (to its slab).
+// KMAX = 32 (the hg4x128 student: K = 32): the dy tile shrinks to [128][40], which takes the block from 83 KB to 75 KB of LDS --
+// TWO blocks per CU instead of one.  The launch is the last weight gradient of a backward, exposed in front of Adam.
+template <int KMAX>
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a, const int logQ, const int mtiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LDD = 64 + 8;                                    // dy tile pitch (K <= 64)
+    constexpr int LDD = KMAX + 8;                                  // dy tile pitch (K <= KMAX)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, P = a.P, Q = a.Q;
     const int rows = 128 >> logQ, prows = 2 * rows + 5, pcols = 2 * Q + 5;
@@ -208,14 +211,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const fpd_stem_t a
         for (int p0 = 0; p0 < 128; p0 += 16) {
             bf16x8 df[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) df[j] = tr_frag_bf16(sD, LDD, p0, j * 32, lane);     // dy^T: rows = couts
+            for (int j = 0; j < KMAX / 32; ++j) df[j] = tr_frag_bf16(sD, LDD, p0, j * 32, lane);     // dy^T: rows = couts
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int tt = wave + 4 * i;                      // tap tile
                 if (tt < KP / 32) {
                     const bf16x8 af = tr_frag_bf16(sA, LDA, p0, tt * 32, lane);              // A^T: cols = taps
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < KMAX / 32; ++j)
                         if (j < KT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[j], af, acc[i][j], 0, 0, 0);
                 }
             }
@@ -291,10 +294,17 @@ int fpd_stem_wgrad_mfma_partials(const fpd_stem_t& a) {
 int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st) {
     int logQ;
     if (!stem_mfma_ok(a, logQ)) return 1;
-    const size_t lds = (size_t)128 * LDA * sizeof(bf16_t) + (size_t)128 * 72 * sizeof(bf16_t) + patch_bytes(logQ);
+    const int kmax = a.K <= 32 ? 32 : 64;
+    const size_t lds = (size_t)128 * LDA * sizeof(bf16_t) + (size_t)128 * (kmax + 8) * sizeof(bf16_t) + patch_bytes(logQ);
     const int tiles = a.N * a.P * a.Q / 128;
-    static LdsAttr cfg;                 // per device, set once (thread-safe: common.h)
-    if (int rc_ = cfg.ensure(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel), lds)) return rc_;
-    FPD_LAUNCH(stem_wgrad_mfma_kernel, dim3(a.partial != nullptr ? std::min(tiles, 512) : 1), dim3(256), lds, st, a, logQ, tiles);
+    const dim3 grid(a.partial != nullptr ? std::min(tiles, 512) : 1);
+    static LdsAttr cfg32, cfg64;        // per device, set once (thread-safe: common.h)
+    if (kmax == 32) {
+        if (int rc_ = cfg32.ensure(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel<32>), lds)) return rc_;
+        FPD_LAUNCH((stem_wgrad_mfma_kernel<32>), grid, dim3(256), lds, st, a, logQ, tiles);
+    } else {
+        if (int rc_ = cfg64.ensure(reinterpret_cast<const void*>(&stem_wgrad_mfma_kernel<64>), lds)) return rc_;
+        FPD_LAUNCH((stem_wgrad_mfma_kernel<64>), grid, dim3(256), lds, st, a, logQ, tiles);
+    }
     return 0;
 }

@@ -112,33 +112,35 @@ def test_hourglass_two_shards_on_one_gpu_match_the_mean_of_shard_gradients():
     def make():
         _, _, s, t = build_models(name)
         return s, t
-    reps = _two_replicas(make, c['batch'], c['image'][1], c['image'][0], 0.5, lr)
+    # global batch 4 = two samples per shard: with ONE sample a shard's train-mode BN normalises the 2x2 maps at the bottom of
+    # this small hourglass over 4 values, and the reference's own fp32 gradient is then 1.0 (of ~40) away from fp64
+    GB = 4
+    reps = _two_replicas(make, GB, c['image'][1], c['image'][0], 0.5, lr)
     assert len(reps[0].step.student.state.table.buckets) >= 2      # one bucket per stack: the bucketed layout is exercised
-    x, tg, tw = _cases.batch(name)
+    x, tg, tw = fpd_ref.synth_batch(100, GB, c['joints'], c['image'], c['heat'])
     _run_shards(reps, x, tg, tw)
     total = _check_buckets_and_reduce(reps)
-    _check_against_single_rank_runs(make, reps, total, x, tg, tw, c['batch'], c['image'][1], c['image'][0], 0.5, lr)
+    _check_against_single_rank_runs(make, reps, total, x, tg, tw, GB, c['image'][1], c['image'][0], 0.5, lr)
     ours = _flat_model_grads(reps[0].model)
     # oracle: per-shard gradients of the per-shard mean loss, averaged over the shards (fp32 and fp64)
     keys = reps[0].model.table.trainable_keys()
     mean32, mean64, losses32, losses64 = 0, 0, [], []
     for r in range(2):
         s_sd, t_sd = _cases.state_dicts(name)
-        g32 = fpd_ref.fpd_step(s_sd, t_sd, c['s'][1], c['t'][1], x[r:r + 1], tg[r:r + 1], tw[r:r + 1], 0.5)
+        g32 = fpd_ref.fpd_step(s_sd, t_sd, c['s'][1], c['t'][1], x[2 * r:2 * r + 2], tg[2 * r:2 * r + 2], tw[2 * r:2 * r + 2], 0.5)
         losses32.append((float(g32['pose']), float(g32['kd'])))
         mean32 = mean32 + torch.cat([g32['grads'][k].reshape(-1) for k in keys]) / 2
         s_sd, t_sd = _cases.state_dicts(name)
         s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in s_sd.items()}
         t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
-        g64 = fpd_ref.fpd_step(s64, t64, c['s'][1], c['t'][1], x[r:r + 1].double(), tg[r:r + 1].double(), tw[r:r + 1].double(), 0.5)
+        g64 = fpd_ref.fpd_step(s64, t64, c['s'][1], c['t'][1], x[2 * r:2 * r + 2].double(), tg[2 * r:2 * r + 2].double(), tw[2 * r:2 * r + 2].double(), 0.5)
         mean64 = mean64 + torch.cat([g64['grads'][k].reshape(-1) for k in keys]) / 2
         losses64.append((float(g64['pose']), float(g64['kd'])))
     for r, rep in enumerate(reps):                         # each rank reports the loss of ITS shard (local mean)
-        # one sample per shard: a scalar loss is ONE realisation of the fp32 rounding noise (measured: ours 8e-5, the
-        # reference's fp32 3e-5 away from fp64 on a kd loss of 0.47) -- an absolute band; the gradient check below is the
+        # a scalar loss is ONE realisation of the fp32 rounding noise: an absolute band; the gradient check below is the
         # statistically meaningful one (thousands of elements, max-norm, fp64 referee)
         for ours_l, r32, r64 in zip(rep.step.losses()[:2], losses32[r], losses64[r]):
-            assert abs(ours_l - r64) <= 2e-4 and abs(ours_l - r32) <= 2e-4, (r, ours_l, r32, r64)
+            assert abs(ours_l - r64) <= 1e-4 and abs(ours_l - r32) <= 1e-4, (r, ours_l, r32, r64)
     _cases.assert_parity(ours.numpy(), mean32.numpy(), mean64.numpy(), 'all-reduced gradient of two shards', floor=5e-6, slack=2.5, atol=3e-5)
     # Adam on both replicas: identical parameters, one update of at most lr per element away from the oracle's
     p_before = reps[0].model.device_state().A.tensor('param').clone()
@@ -168,12 +170,13 @@ def test_hrnet_two_shards_bucketed_reduction_equals_single_reduction():
     def make():
         s, t, _, _ = build_pair()
         return s, t
-    reps = _two_replicas(make, c['batch'], H, W, c['alpha'], 1e-3)
+    GB = 4                                                  # two samples per shard (see the hourglass test)
+    reps = _two_replicas(make, GB, H, W, c['alpha'], 1e-3)
     assert len([b for b in reps[0].step.student.state.table.buckets if b[1] > b[0]]) >= 3      # stage buckets
-    x, tg, tw = fpd_ref.synth_batch(100, c['batch'], c['joints'], c['image'], c['heat'])
+    x, tg, tw = fpd_ref.synth_batch(100, GB, c['joints'], c['image'], c['heat'])
     _run_shards(reps, x, tg, tw)
     total = _check_buckets_and_reduce(reps)
-    _check_against_single_rank_runs(make, reps, total, x, tg, tw, c['batch'], H, W, c['alpha'], 1e-3)
+    _check_against_single_rank_runs(make, reps, total, x, tg, tw, GB, H, W, c['alpha'], 1e-3)
     ours = _flat_model_grads(reps[0].model).double()
     ex_s, ex_t = extra_cfg(c['s']), extra_cfg(c['t'])
     s_sd = fpd_ref.synth_state_dict(hrnet_ref.hrnet_keys(ex_s, c['joints']), 1)
@@ -185,19 +188,18 @@ def test_hrnet_two_shards_bucketed_reduction_equals_single_reduction():
     for r in range(2):
         s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in copy.deepcopy(s_sd).items()}
         t64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in t_sd.items()}
-        g = fpd_ref.fpd_step(s64, t64, 1, 1, x[r:r + 1].double(), tg[r:r + 1].double(), tw[r:r + 1].double(), c['alpha'], **fwd)
+        g = fpd_ref.fpd_step(s64, t64, 1, 1, x[2 * r:2 * r + 2].double(), tg[2 * r:2 * r + 2].double(), tw[2 * r:2 * r + 2].double(), c['alpha'], **fwd)
         mean64 = mean64 + torch.cat([g['grads'][k].reshape(-1) for k in names]) / 2
-        g = fpd_ref.fpd_step(copy.deepcopy(s_sd), copy.deepcopy(t_sd), 1, 1, x[r:r + 1], tg[r:r + 1], tw[r:r + 1], c['alpha'], **fwd)
+        g = fpd_ref.fpd_step(copy.deepcopy(s_sd), copy.deepcopy(t_sd), 1, 1, x[2 * r:2 * r + 2], tg[2 * r:2 * r + 2], tw[2 * r:2 * r + 2], c['alpha'], **fwd)
         mean32 = mean32 + torch.cat([g['grads'][k].reshape(-1) for k in names]).double() / 2
     rel = float((ours - mean64).norm() / mean64.norm())
     rel32 = float((mean32 - mean64).norm() / mean64.norm())
     # Against the oracle the figure is dominated by ReLU-kink flips (a pre-activation within rounding distance of zero takes the
-    # other branch: ~1e-3 of the gradient each, tests/test_hrnet_graph_cpu.py), and one sample per shard on 3x4 ... 24x32 maps
-    # has few elements to average them over: measured 1.0e-2 here where torch's own fp32 happened to flip none (7e-6).  The
-    # bound is therefore a gross-error bound (a wrong 1/world or a missed bucket is an error of order 1); the arithmetic of the
-    # world > 1 path itself is pinned to 1e-5 by _check_against_single_rank_runs above.
+    # other branch: ~1e-3 of the gradient each, tests/test_hrnet_graph_cpu.py; with ONE sample per shard it was 1.0e-2 where
+    # torch's own fp32 happened to flip none).  A gross-error bound (a wrong 1/world or a missed bucket is an error of order
+    # 1); the arithmetic of the world > 1 path itself is pinned to 1e-5 by _check_against_single_rank_runs above.
     print('hrnet two shards: gradient rel-L2 vs fp64 %.2e (reference fp32: %.2e)' % (rel, rel32))
-    assert rel <= 3e-2, (rel, rel32)
+    assert rel <= 1.5e-2, (rel, rel32)
     for rep in reps:
         rep.step.flush()
     torch.cuda.synchronize()
