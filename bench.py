@@ -191,8 +191,11 @@ def conv_classes(step, R, peak_tflops, launches=12, top=6):
         nbytes = 2.0 * (n * h * w * C + n * P * Q * K)
         if o.kind == 'conv' and getattr(o, 'residual', None) is not None:
             nbytes += 2.0 * n * P * Q * K
+        # the shape tag the library's launch log gives this launch (csrc/api.hip set_op_tag): the key of profiles/*_hbm_traffic.csv
+        tag = ('wgrad N=%d H=%d W=%d C=%d K=%d R=%d s=%d' % (n, h, w, C, K, Rr, stride) if o.kind == 'wgrad' else
+               'conv N=%d H=%d W=%d C=%d K=%d R=%d s=%d %s' % (n, h, w, C, K, Rr, stride, 'dgrad' if kind == 'data gradient' else 'fwd'))
         out.append({'role': role, 'kind': kind, 'conv': '%dx%d %d->%d stride %d on %dx%dx%d' % (Rr, S, C, K, stride, n, h, w),
-                    'launches_per_step': count, 'flops': flops, 'bytes': nbytes, '_plan': plan, '_k': k})
+                    'launches_per_step': count, 'flops': flops, 'bytes': nbytes, 'shape_tag': tag, '_plan': plan, '_k': k})
     # time the classes that can matter (largest algorithmic cost first; a class whose roofline time is tiny can still be slow,
     # so the cut is generous)
     for e in out:
@@ -205,6 +208,24 @@ def conv_classes(step, R, peak_tflops, launches=12, top=6):
         e['us'] = round(e['us'], 2)
     out.sort(key=lambda e: -e['ms_per_step'])
     return out[:top], round(sum(e['ms_per_step'] for e in out), 3)
+
+
+def pmc_traffic_of_class(shape_tag, sub):
+    """HBM bytes per launch of a convolution class from the committed rocprofv3 --pmc passes of this round, keyed on the shape
+    tag of the library's launch log (profiles/r04_<sub>hbm_traffic.csv, written by tools/profile_summarize.py); (None, why)
+    if that table or row is absent."""
+    import csv
+    for pfx in ('r04', 'r04a'):
+        path = os.path.join(ROOT, 'profiles', '%s_%shbm_traffic.csv' % (pfx, sub))
+        if not os.path.exists(path):
+            continue
+        rows = [r for r in csv.DictReader(open(path)) if r['shape'].startswith(shape_tag)]
+        if rows:
+            r = max(rows, key=lambda r: int(r['launches_counted']))
+            return float(r['hbm_MB_per_launch']) * 1e6, 'profiles/%s_%shbm_traffic.csv: %s, "%s" (%s launches counted)' % (
+                pfx, sub, r['kernel'], r['shape'], r['launches_counted'])
+        return None, 'profiles/%s_%shbm_traffic.csv has no row for "%s"' % (pfx, sub, shape_tag)
+    return None, 'no PMC pass for this configuration under profiles/'
 
 
 def dominant_kernel(step, R, launches=50):
@@ -478,7 +499,7 @@ def main():
         # HBM bytes/launch from separate rocprofv3 --pmc passes (tools/pmc_bneck.sh), only if that file was measured at the
         # launch geometry timed here (grid cap): a file from another geometry is refused, not quoted
         traffic, traffic_note = None, 'no PMC file under profiles/'
-        for name in ('r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
+        for name in ('r04_pmc_bneck64.json', 'r04a_pmc_bneck64.json', 'r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
@@ -506,8 +527,9 @@ def main():
             ach, pk, unit = d['bytes'] / (d['us'] * 1e-6) / 1e9, 8000.0, 'GB/s'
         else:
             ach, pk, unit = d['flops'] / (d['us'] * 1e-6) / 1e12, peak, 'TFLOP/s'
+        traffic, tsrc = pmc_traffic_of_class(d['shape_tag'], 'hrnet_' if hr else '')
         roofline = {'bound': d['bound'], 'achieved': round(ach, 2), 'peak': pk, 'unit': unit, 'frac': round(ach / pk, 4),
-                    'traffic': None, 'traffic_source': 'no PMC pass for this kernel yet (profiles/README.md)',
+                    'traffic': traffic, 'traffic_source': tsrc,
                     'kernel': '%s %s, %s' % (d['role'], d['kind'], d['conv']), 'avg_us': d['us'],
                     'flop_per_launch': d['flops'], 'algorithmic_bytes_per_launch': d['bytes'],
                     'launches_per_step': d['launches_per_step'],

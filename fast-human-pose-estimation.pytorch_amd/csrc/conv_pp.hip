@@ -132,6 +132,23 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         const int tl = pp_fresh(tid);
         const int cve = (tl & (CPR - 1)) * 8;
         hmask = 0;
+        if constexpr (R == 1) {
+            // no halo: a tile is TPX consecutive pixels of the NHWC tensor, vector v is pixel v / CPR of the tile -- no row / column
+            // arithmetic at all (this loop is VALU-bound: 513 vector instructions per tile and wave before, r04 ISA count)
+            const int m0t = tile * TPX;
+#pragma unroll
+            for (int i = 0; i < NVH; ++i) {
+                if (i < nvh) {
+                    const int v = min(tl + i * 512, nvtot - 1);
+                    const int m = m0t + (v >> LOG_CPR);
+                    const size_t off = (size_t)min(m, M - 1) * C + cve;
+                    rh[i] = *reinterpret_cast<const uint4*>(x + off);
+                    if (BWD && fold) ru[i] = *reinterpret_cast<const uint4*>(fx + off);
+                    hmask |= (m < M ? 1u : 0u) << i;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
             if (i < nvh) {
@@ -185,8 +202,9 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             if (i < nvh) {
                 const int v = tl + i * 512;
                 const int vc = min(v, nvtot - 1);
-                const int hr = pp_qdiv(vc, geo.mWV);
-                const int j = (vc - hr * WV) >> LOG_CPR;
+                int hr, j;
+                if constexpr (R == 1) { hr = 0; j = vc >> LOG_CPR; }        // (pixel of the tile: rows are contiguous without a halo)
+                else { hr = pp_qdiv(vc, geo.mWV); j = (vc - hr * WV) >> LOG_CPR; }
                 uint4 val = rh[i];
                 if (BWD && fold) {
                     float g[8], u[8];
@@ -203,7 +221,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                     // the evaluated operand is written out once for its other consumers (a separate weight-gradient launch):
                     // rows of this tile proper only -- halo rows belong to the neighbouring tiles
                     if (fo != nullptr && in && v < nvtot && hr >= pad && hr < pad + nrows)
-                        *reinterpret_cast<uint4*>(fo + ((size_t)((g0s + hr) * W + j) * C + (cvb >> 1))) = val;
+                        *reinterpret_cast<uint4*>(fo + ((size_t)((g0s + hr) * W + j) * C + (cvb >> 1))) = val;     // (R == 1: g0s * W + j = the pixel)
                 }
                 if (WG && wg_bias) {
                     float f[8];
@@ -225,7 +243,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                     val.x = in ? val.x : 0u; val.y = in ? val.y : 0u; val.z = in ? val.z : 0u; val.w = in ? val.w : 0u;
                 }
                 // threads past the last vector of a ragged tile write to the spare 16 bytes behind the zero pixels
-                const int dst = v < nvtot ? (hr * WP + j + pad) * LDA + cvb : (zero_px + 3) * LDA;
+                const int dst = v < nvtot ? (R == 1 ? j : hr * WP + j + pad) * LDA + cvb : (zero_px + 3) * LDA;
                 *reinterpret_cast<uint4*>(sG + dst) = val;
             }
         }
@@ -313,6 +331,11 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     const int ti = pp_qdiv(ml, geo.mW), tj = ml - ti * W;
     int ab[3];
     auto tile_addr = [&](int tile) {
+        if constexpr (R == 1) {                           // pixel ml of the tile sits at image pixel ml
+            const bool live1 = tile * TPX + ml < M && ml < TPX;
+            ab[0] = ab[1] = ab[2] = live1 ? ml * LDA : zero_px * LDA;
+            return;
+        }
         const int g = tile * nrows + ti;
         const int p = g - pp_qdiv(g, geo.mH) * H;
         const bool live = g < GR && ml < TPX;
@@ -706,8 +729,18 @@ static bool pp_domain(const fpd_conv_t& a) {
 }
 static int pp_tiles(const fpd_conv_t& a) { return cdiv(a.N * a.H, pp_nrows(a)); }
 // shapes whose data-gradient launch can carry the forward convolution's weight gradient (conv_pp_body<.., WG = true>)
+static int pp_wg_kmax() {   // FPD_CONV_PP_WGRAD_KMAX: widest data gradient (output channels) that also forms the weight gradient
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD_KMAX"); v = e ? atoi(e) : 128; }
+    return v;
+}
+static int pp_wg_ckmax() {  // FPD_CONV_PP_WGRAD_CKMAX: largest weight matrix (C x K elements) formed inside a data-gradient launch
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD_CKMAX"); v = e ? atoi(e) : 128 * 128; }
+    return v;
+}
 static bool pp_wg_shape(const fpd_conv_t& a) {
-    return pp_fuse_wgrad() != 0 && pp_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && a.R == 1 && a.C >= 32 &&
+    return pp_fuse_wgrad() != 0 && pp_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && a.R == 1 && a.C >= 32 && a.K <= pp_wg_kmax() && a.C * a.K <= pp_wg_ckmax() &&
            (pp_nrows(a) * a.W) % 16 == 0;
 }
 
