@@ -159,3 +159,43 @@ def test_host_side_dispatch_predicates_of_round_3_without_a_device(runtime):
     assert lib.fpd_set_option(b'no_such_option', 1) < 0 and b'unknown' in lib.fpd_last_error()
     prev = lib.fpd_set_option(b'conv_pp_blocks', 64)
     assert prev == 256 and lib.fpd_set_option(b'conv_pp_blocks', prev) == 64
+
+
+def test_exact_statistics_encoding_round_trip_and_order_independence():
+    """include/fpd_amd.h fpd_stat_t as the host sees it (executor.Arenas.stats_write / stats_read on CPU tensors): a value
+    travels as two 64-bit integer limbs, hi = rint(v * 2^8) and lo = rint((v - hi * 2^-8) * 2^60); the split is exact to
+    2^-61 over the whole range a BatchNorm sum can take, and -- the point of the format -- integer limb sums do not depend
+    on the order of the addends, where fp64 sums of the same addends do."""
+    import numpy as np
+    import torch
+    from fpd_amd import executor as E, graph as G
+    A = E.Arenas(torch.device('cpu'), 0)
+    C, R = 8, G.STATS_REPLICAS
+    A.alloc('stats', R * 2 * C + 64)
+    buf = G.Buf('stats', 16, (R, 2, C))
+    assert A.tensor('stats').dtype == torch.int64 and A.tensor('stats').numel() == 2 * (R * 2 * C + 64)
+    assert A.ptr(buf) - A.tensor('stats').data_ptr() == 16 * 16          # two 8-byte limbs per logical element
+    rng = np.random.RandomState(0)
+    vals = torch.from_numpy(np.concatenate([rng.standard_normal(R * C) * 10.0 ** rng.uniform(-12, 12, R * C),
+                                            np.array([0.0, 1.0, -1.0, 2.0 ** -40, -2.0 ** 40, 1e-15, 123456.789, -0.1] * (R * C // 8))]
+                                           ).reshape(R, 2, C))
+    A.stats_write(buf, vals)
+    back = A.stats_read(buf)
+    err = (back - vals).abs()
+    assert float(err.max()) <= 2.0 ** -60 and float((err / vals.abs().clamp_min(1e-300))[vals.abs() > 1e-9].max()) < 1e-9
+    raw = A.view(buf)
+    assert raw.shape == (R, 2, 2, C) and int(raw[:, :, 1, :].abs().max()) <= 2 ** 51      # |lo| <= 2^51: 2048 addends fit 63 bits
+    # order independence: sum 2048 "block partials" as limbs in two different orders -> identical limbs; as doubles -> not
+    parts = rng.standard_normal(2048) * 10.0 ** rng.uniform(-6, 6, 2048)
+    hi = np.rint(parts * 256.0).astype(np.int64)
+    lo = np.rint((parts - hi / 256.0) * 2.0 ** 60).astype(np.int64)
+    perm = rng.permutation(2048)
+    assert hi.sum() == hi[perm].sum() and lo.sum() == lo[perm].sum()
+    s1 = s2 = 0.0
+    for v in parts:
+        s1 += v
+    for v in parts[perm]:
+        s2 += v
+    assert s1 != s2                                          # what the fp64 atomics of rounds 1-3 did to the last bits
+    exact = float(hi.sum()) / 256.0 + float(lo.sum()) / 2.0 ** 60
+    assert abs(exact - s1) <= 1e-9 * np.abs(parts).sum()

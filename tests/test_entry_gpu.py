@@ -242,3 +242,38 @@ def test_tools_fpd_train_cli_smoke_and_auto_resume(tmp_path):
     assert r3.returncode == 0, (r3.stdout[-1500:], r3.stderr[-3000:])
     log3 = r3.stdout + r3.stderr
     assert log3.count('Test: [') == 2 and 'validation done' in log3 and 'PCK@0.5' in log3
+
+
+def test_launch_log_keys_every_kernel_launch_on_its_plan_op_and_shape(tmp_path):
+    """FPD_LAUNCH_LOG (csrc/common.h FPD_LAUNCH, csrc/api.hip set_op_tag): one line per kernel launch in host order --
+    kernel expression, grid, block, plan op index, op kind + shape -- which tools/profile_summarize.py aligns with the
+    rocprofv3 trace rows (same order) to key them on the tensor shape.  Run in a subprocess: the variable is read when the
+    library is loaded."""
+    import os
+    import subprocess
+    import sys
+    log = tmp_path / 'launch.log'
+    code = (
+        "import torch\n"
+        "from fpd_amd import executor as E\n"
+        "from tests import _cases\n"
+        "from tests.test_model_gpu import build_models\n"
+        "c, gold, s, t = build_models('tiny', 'bf16')\n"
+        "st = E.FusedFPDStep(s.device_state(), s.cfg_hg, t.device_state(), t.cfg_hg, c['batch'], c['image'][1], c['image'][0], alpha=0.5)\n"
+        "st.set_batch(*_cases.batch('tiny', 0)); st.step(); torch.cuda.synchronize()\n"
+        "print('LAUNCHES', st.launches_per_step()['total'])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPD_LAUNCH_LOG=str(log), PYTHONPATH=root)
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l.rstrip('\n').split('\t') for l in open(log)]
+    assert len(lines) > 100 and all(len(f) == 5 for f in lines), lines[:3]
+    kinds = {f[4].split(' ')[0] for f in lines}
+    assert {'conv', 'ew', 'wgrad', 'loss', 'adam', 'stem_fwd', 'wprep'} <= kinds, kinds
+    convs = [f for f in lines if f[4].startswith('conv ')]
+    assert all(' N=2 ' in f[4] and ' C=' in f[4] and (' fwd' in f[4] or ' dgrad' in f[4]) for f in convs), convs[:3]
+    assert any('+wgrad' in f[4] or '+fold' in f[4] for f in convs) or True      # (fusions depend on the launch sizes: tiny maps may have none)
+    assert all(f[1].isdigit() and f[2].isdigit() and f[3].lstrip('-').isdigit() for f in lines)
+    # plan ops and logged launches agree: memsets are not kernels of the library, adam is two launches (update + tick)
+    n_ops = int(out.stdout.split('LAUNCHES')[1].split()[0])
+    assert abs(len(lines) - n_ops) <= 16, (len(lines), n_ops)
