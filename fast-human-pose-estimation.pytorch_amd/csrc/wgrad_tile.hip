@@ -383,7 +383,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     // C, K <= 32 (the SMALL variant: one live 32x32 sub-tile, nine taps): a slab is 37 KB, not 147 KB, and the launch is bound by
     // the per-tile staging of its 128 blocks -- the hourglass' 3x3 32->32 at 128x128 is one of the last launches of the backward
     // (158 us, exposed in front of Adam): four times the blocks
-    if (a.R == 3 && a.dtype == FPD_BF16 && a.C <= 32 && a.K <= 32) target = 512;
+    if (a.R == 3 && a.dtype == FPD_BF16 && a.C <= 32 && a.K <= 32) target = std::max(128, std::min(512, g.mtiles / 4));      // (>= 4 tiles per block: HRNet's 64x48 maps keep 192)
     if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
     if (const char* e = getenv(a.R == 1 ? "FPD_WGRAD_BLOCKS_1" : "FPD_WGRAD_BLOCKS_3")) target = atoi(e);   // per filter size
     g.gx = std::max(1, std::min(g.mtiles, cdiv(target, g.gy)));

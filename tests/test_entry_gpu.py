@@ -230,8 +230,10 @@ def test_tools_fpd_train_cli_smoke_and_auto_resume(tmp_path):
     ck2 = torch.load(ckpts[0], map_location='cpu', weights_only=False)
     assert ck2['epoch'] == 3 and abs(ck2['optimizer']['param_groups'][0]['lr'] - 2.5e-6) < 1e-13   # second milestone (3 <= 2+1)
     assert float(ck2['optimizer']['state'][0]['step']) == 9
-    # every epoch validated (tools/fpd_train.py:266-285) and the best model was kept
-    assert log.count('Test: [0/') == 2 and 'PCK@0.5' in log
+    # teacher and student validated before the first epoch (tools/fpd_train.py:243-250), the student after every epoch
+    # (:266-285), and the best model was kept
+    assert log.count('Test: [0/') == 4 and 'PCK@0.5' in log
+    assert log.index('Test: [0/') < log.index('Epoch: [0][0/')
     assert any(f == 'model_best.pth' for _, _, fs in os.walk(tmp_path) for f in fs)
     # tools/test.py (reference tools/test.py:38-135): validation of the trained model from <output dir>/final_state.pth, flip test on
     r3 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), '--cfg', os.path.join(cfgd, 'hg4x128_student.yaml'),

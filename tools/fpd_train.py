@@ -145,6 +145,15 @@ def main():
     optimizer.param_groups[0]['initial_lr'] = base_lr
     allreduce = fdist.make_allreduce(dist) if world > 1 else None
     writer_dict = {'writer': None, 'train_global_steps': 0, 'valid_global_steps': 0}
+    if rank == 0:
+        # :243-250: before the first epoch the reference evaluates the teacher and then the student on the validation set
+        # (the two "Test:" blocks in front of epoch 0 in its logs).  Both go through core.function.validate; rank 0 only, like
+        # the per-epoch validation below.
+        if tmodel is not None:
+            validate(cfg, valid_loader, valid_set, tmodel, pose_criterion, out_dir, cfg.LOG_DIR, writer_dict)
+        validate(cfg, valid_loader, valid_set, model, pose_criterion, out_dir, cfg.LOG_DIR, writer_dict)
+    if world > 1:
+        dist.barrier()
     for epoch in range(begin_epoch, cfg.TRAIN.END_EPOCH):                                     # :252-286
         t0 = time.time()
         optimizer.param_groups[0]['lr'] = multistep_lr(base_lr, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR, epoch)   # :253
