@@ -256,3 +256,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Probe build only (tools/probes/tile_timing.sh, -DFPD_TILE_TIMING): cycle stamps of block (0, 0) at the phase boundaries of
+// conv_tile_body and its epilogue, printed by the kernel.
+#ifdef FPD_TILE_TIMING
+__shared__ long long fpd_tile_stamp[32];
+__shared__ int fpd_tile_ns;
+#define TILE_STAMP() do { if (threadIdx.x == 0 && fpd_tile_ns < 32) fpd_tile_stamp[fpd_tile_ns++] = clock64(); } while (0)
+#else
+#define TILE_STAMP() do { } while (0)
+#endif

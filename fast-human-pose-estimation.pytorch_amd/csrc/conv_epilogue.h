@@ -149,6 +149,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     };
     request(0);
     __syncthreads();                                       // tile region free: every wave is past its last MFMA LDS read
+    TILE_STAMP();
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -157,6 +158,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
         }
     __syncthreads();
+    TILE_STAMP();
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g > 0) request(g);
@@ -218,6 +220,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             }
         }
     }
+    TILE_STAMP();
     if (want_stats) {
         double s1[VEC], s2[VEC];
         if constexpr (sizeof(T) == 2) {
@@ -272,6 +275,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
         }
         }
         __syncthreads();                                   // staging tile no longer read: s_red may alias it
+        TILE_STAMP();
         if (lane < CVN) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -280,6 +284,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             }
         }
         __syncthreads();
+        TILE_STAMP();
         fpd_stat_t* st = bwd ? a.epi_stats : a.out_stats;
         for (int t = tid; t < BNT; t += 256) {
             const int k = n0 + t;
@@ -291,5 +296,6 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
                 stat_atomic_add(st, K, 1, k, u2);
             }
         }
+        TILE_STAMP();
     }
 }

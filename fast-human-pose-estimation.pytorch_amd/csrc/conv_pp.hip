@@ -27,6 +27,7 @@
 // Replaces the same reference calls as conv_tile (nn.Conv2d + BatchNorm2d + ReLU, /root/reference/lib/models/hourglass.py:18-52).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -51,6 +52,27 @@ static inline unsigned pp_magic(int d) { return (unsigned)((0x100000000ull / (un
 __device__ __forceinline__ int pp_fresh(int v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+
+// Two bf16 of a dword as two floats and back: the forward arithmetic below is written on PAIRS (v_pk_fma_f32 / v_pk_add_f32 /
+// v_pk_mul_f32, v_pk_max_i16 on the packed result) -- the same operation per element in the same order as the scalar form, so the
+// same bits, at fewer vector instructions (r04 ISA count of the 1x1 128->64 forward tile loop: 513 -> 406 per tile and wave,
+// against 8 MFMAs).  Measured (r04, interleaved A/B + per-shape trace A/B): 2-4 % on the 1x1 forward launches in isolation, nothing
+// on the step -- the tile loop is bound by its barriers and LDS round trips, not by VALU issue.  The BN-backward epilogue stays
+// scalar: its packed form was 2-7 % slower on the +wgrad +fold kernels (more registers, longer dependent chains).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bf2_unpack(unsigned w) {
+    f32x2 r = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    return r;
+}
+__device__ __forceinline__ unsigned bf2_pack(f32x2 v) { return f2bf_pk(v[0], v[1]); }
+// max of the two signed 16-bit halves with `lo` in both: lo = 0 is ReLU on a packed bf16 pair (a negative bf16 is a negative
+// int16; rounding is monotonic and keeps the sign, so relu(round(t)) == round(relu(t))), lo = -32768 is the identity
+__device__ __forceinline__ unsigned bf2_floor(unsigned w, short lo) {
+    s16x2 a = *reinterpret_cast<const s16x2*>(&w);
+    const s16x2 b = {lo, lo};
+    a = __builtin_elementwise_max(a, b);
+    return *reinterpret_cast<const unsigned*>(&a);
 }
 
 #ifdef FPD_PP_TIMING      // probe build only (tools/probes): cycle stamps of two blocks at the phase boundaries, printed by the kernel
@@ -163,7 +185,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             }
         }
     };
-    const float relu_lo = a.bn.relu ? 0.f : -3.4e38f;
+    const short relu_floor = a.bn.relu ? (short)0 : (short)-32768;       // see bf2_floor
     float bs[8];                                          // WG: this thread's share of sum_pixels dy[., 8 channels]
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[e] = 0.f;
@@ -231,16 +253,17 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                     for (int e = 0; e < 8; ++e) bs[e] = fmaf(f[e], cnt, bs[e]);
                 }
                 if (has_bn) {
-                    float f[8];
-                    DT<bf16_t>::unpack(val, f);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[e] = fmaxf(fmaf(f[e], sc0[e], sh0[e]), relu_lo);
-                        f[4 + e] = fmaxf(fmaf(f[4 + e], sc1[e], sh1[e]), relu_lo);
+                    // a = relu?(x * scale + shift), rounded once: fma on pairs, ReLU on the packed result
+                    const f32x2 s0 = {sc0[0], sc0[1]}, s1 = {sc0[2], sc0[3]}, s2 = {sc1[0], sc1[1]}, s3 = {sc1[2], sc1[3]};
+                    const f32x2 h0 = {sh0[0], sh0[1]}, h1 = {sh0[2], sh0[3]}, h2 = {sh1[0], sh1[1]}, h3 = {sh1[2], sh1[3]};
+                    val.x = bf2_floor(bf2_pack(__builtin_elementwise_fma(bf2_unpack(val.x), s0, h0)), relu_floor);
+                    val.y = bf2_floor(bf2_pack(__builtin_elementwise_fma(bf2_unpack(val.y), s1, h1)), relu_floor);
+                    val.z = bf2_floor(bf2_pack(__builtin_elementwise_fma(bf2_unpack(val.z), s2, h2)), relu_floor);
+                    val.w = bf2_floor(bf2_pack(__builtin_elementwise_fma(bf2_unpack(val.w), s3, h3)), relu_floor);
+                    if constexpr (R != 1) {               // halo rows outside the tensor stay exactly zero (a 1x1 convolution has
+                        const bool in = (hmask >> i) & 1u;    // no halo: pixels past the tensor are dead lanes that read the zero pixel)
+                        val.x = in ? val.x : 0u; val.y = in ? val.y : 0u; val.z = in ? val.z : 0u; val.w = in ? val.w : 0u;
                     }
-                    val = DT<bf16_t>::pack(f);
-                    const bool in = (hmask >> i) & 1u;    // rows outside the tensor stay exactly zero
-                    val.x = in ? val.x : 0u; val.y = in ? val.y : 0u; val.z = in ? val.z : 0u; val.w = in ? val.w : 0u;
                 }
                 // threads past the last vector of a ragged tile write to the spare 16 bytes behind the zero pixels
                 const int dst = v < nvtot ? (R == 1 ? j : hr * WP + j + pad) * LDA + cvb : (zero_px + 3) * LDA;
@@ -351,10 +374,10 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
 
     // ---- epilogue state: a lane reads back the 8-channel chunk cv4 of rows r16, r16 + 16 of its wave's 32 px x 32 ch block ----
     uint4 rres[2], rex[BWD ? 2 : 1];
-    float f1[8], f2[8], cshift[8];
+    f32x2 F1[4], F2[4], CS[4];                            // statistics partials / common shift of this lane's 8 channels, as pairs
     int nrow = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { f1[e] = 0.f; f2[e] = 0.f; cshift[e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { F1[e] = f32x2{0.f, 0.f}; F2[e] = f32x2{0.f, 0.f}; CS[e] = f32x2{0.f, 0.f}; }
     const float relu_gate = a.epi_bn.relu ? 0.f : -3.4e38f;
     const int kw0 = n0 + hc * 32;                         // first channel of this wave's block
     auto request = [&](int tile) {                        // residual / epi_x vectors of `tile`
@@ -373,7 +396,8 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     f32x16 wacc;                                          // WG: this wave's 32x32 tile of dW (its share of the pixel steps)
 #pragma unroll
     for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
-    auto epilogue = [&](int tile, const bool first) {
+    auto epilogue = [&](int tile, auto firstc) {
+        constexpr bool first = decltype(firstc)::value;    // the block's first tile (peeled: it alone picks the shift of the sums)
         const int ln = pp_fresh(lane);
         const int cv4 = ln & 3, r16 = ln >> 2;
         unsigned char* stg = sS + wave * (32 * LDST);     // wave-private [32 px][LDST]
@@ -394,30 +418,34 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             const int m = tile * TPX + px;
             const bool ok = px < TPX && m < M && k0 < K;
             const float live = ok ? 1.f : 0.f;
+            const f32x2 live2 = {live, live};
             const unsigned rr[4] = {rres[it].x, rres[it].y, rres[it].z, rres[it].w};
             const unsigned xr[4] = {rex[BWD ? it : 0].x, rex[BWD ? it : 0].y, rex[BWD ? it : 0].z, rex[BWD ? it : 0].w};
             unsigned pw[4];
             unsigned aw[4] = {0u, 0u, 0u, 0u};            // WG: bf16 a(u) of this row's 8 channels
-            // 4 channels at a time; the per-channel tables are re-read from the LDS (laundered address) instead of living in
+            // 4 channels at a time, as two pairs (packed fp32 arithmetic: the same operation per element in the same order as
+            // the scalar form); the per-channel tables are re-read from the LDS (laundered address) instead of living in
             // registers across the tile loop: v = acc + residual + bias, rounded once
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int klq = pp_fresh(kl) + 4 * q;
+                const int p0 = 2 * q, p1 = 2 * q + 1;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * LDST + cv4 * 32 + 16 * q);
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(s_bias + klq);
-                float v[4];
+                if constexpr (BWD) {
+                    // (scalar form: the packed form of this branch measured 2-7 % SLOWER on the +wgrad +fold kernels, r04 trace A/B)
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = t[e];
-                if (res != nullptr) {
+                    for (int e = 0; e < 4; ++e) v[e] = t[e];
+                    if (res != nullptr) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned wd = rr[2 * q + (e >> 1)];
-                        v[e] += __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned wd = rr[2 * q + (e >> 1)];
+                            v[e] += __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        }
                     }
-                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bq[e];
-                if (BWD) {
+                    for (int e = 0; e < 4; ++e) v[e] += bq[e];
                     // ReLU mask of the forward tensor + the two BatchNorm-backward sums
                     const float* te = s_epi + klq;
                     const f32x4 esc = *reinterpret_cast<const f32x4*>(te);
@@ -437,48 +465,48 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
                         float az[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) az[e] = fmaxf(fmaf(xv[e], esc[e], esh[e]), relu_gate);
-                        aw[2 * q] = ok ? f2bf_pk(az[0], az[1]) : 0u;
-                        aw[2 * q + 1] = ok ? f2bf_pk(az[2], az[3]) : 0u;
+                        aw[p0] = ok ? f2bf_pk(az[0], az[1]) : 0u;
+                        aw[p1] = ok ? f2bf_pk(az[2], az[3]) : 0u;
                     }
-                    pw[2 * q] = f2bf_pk(v[0], v[1]);
-                    pw[2 * q + 1] = f2bf_pk(v[2], v[3]);
+                    pw[p0] = f2bf_pk(v[0], v[1]);
+                    pw[p1] = f2bf_pk(v[2], v[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {                    // the stored (rounded) gradient is what gets summed
                         const unsigned wd = pw[2 * q + (e >> 1)];
                         const float g = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16)) * live;
-                        f1[4 * q + e] += g;
-                        f2[4 * q + e] = fmaf(g, (xv[e] - emu[e]) * eis[e], f2[4 * q + e]);
+                        F1[2 * q + (e >> 1)][e & 1] += g;
+                        F2[2 * q + (e >> 1)][e & 1] = fmaf(g, (xv[e] - emu[e]) * eis[e], F2[2 * q + (e >> 1)][e & 1]);
                     }
                 } else {
-                    pw[2 * q] = f2bf_pk(v[0], v[1]);
-                    pw[2 * q + 1] = f2bf_pk(v[2], v[3]);
+                    f32x2 v0 = {t[0], t[1]}, v1 = {t[2], t[3]};
+                    if (res != nullptr) {
+                        v0 += bf2_unpack(rr[p0]);
+                        v1 += bf2_unpack(rr[p1]);
+                    }
+                    v0 += f32x2{bq[0], bq[1]};
+                    v1 += f32x2{bq[2], bq[3]};
+                    pw[p0] = bf2_pack(v0);
+                    pw[p1] = bf2_pack(v1);
                     if (want_stats) {
-                        if (first && it == 0) {
+                        if constexpr (first) if (it == 0) {
                             // the shift of the shifted sums must be COMMON to the 16 lanes that own a channel chunk: the rounded
                             // value of the wave's first pixel row (lanes r16 == 0 hold it), handed over through the LDS
                             float* sh = reinterpret_cast<float*>(stg) + cv4 * 8 + 4 * q;      // (row 0 of the staging tile was read above)
                             if (r16 == 0) {
-                                f32x4 c4;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const unsigned wd = pw[2 * q + (e >> 1)];
-                                    c4[e] = ok ? __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16)) : 0.f;
-                                }
+                                const f32x2 a0 = bf2_unpack(pw[p0]), a1 = bf2_unpack(pw[p1]);
+                                f32x4 c4 = {ok ? a0[0] : 0.f, ok ? a0[1] : 0.f, ok ? a1[0] : 0.f, ok ? a1[1] : 0.f};
                                 *reinterpret_cast<f32x4*>(sh) = c4;
                             }
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             const f32x4 c4 = *reinterpret_cast<const f32x4*>(sh);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) cshift[4 * q + e] = c4[e];
+                            CS[p0] = f32x2{c4[0], c4[1]};
+                            CS[p1] = f32x2{c4[2], c4[3]};
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned wd = pw[2 * q + (e >> 1)];
-                            const float vr = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
-                            const float d = (vr - cshift[4 * q + e]) * live;
-                            f1[4 * q + e] += d;
-                            f2[4 * q + e] = fmaf(d, d, f2[4 * q + e]);
-                        }
+                        const f32x2 d0 = (bf2_unpack(pw[p0]) - CS[p0]) * live2, d1 = (bf2_unpack(pw[p1]) - CS[p1]) * live2;
+                        F1[p0] += d0;
+                        F1[p1] += d1;
+                        F2[p0] = __builtin_elementwise_fma(d0, d0, F2[p0]);
+                        F2[p1] = __builtin_elementwise_fma(d1, d1, F2[p1]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);        // (the two halves one after the other: fewer live temporaries)
@@ -492,7 +520,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
 
     // =========================== the tile loop ===========================
     // Weight fragment of (tap, kk): row hc*32 + l31 of tile `tap`, 16-byte chunk (2 kk + hh) ^ sw(row); sw(l31 + 32) == sw(l31).
-    for (int tile = t_beg; tile < t_end; ++tile) {
+    auto do_tile = [&](int tile, auto firstc) {
         halo_store(tile);                                 // BN+ReLU / folded BN-backward apply on the way into the operand image
         if (tile + 1 < t_end) halo_load(tile + 1);        // in flight during this tile's MFMAs and epilogue
         if (res != nullptr || BWD) request(tile);
@@ -518,7 +546,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         PP_STAMP();
         if (!WG) __syncthreads();                         // every wave is done reading the image: staging tiles may overwrite it
         PP_STAMP();
-        epilogue(tile, tile == t_beg);
+        epilogue(tile, firstc);
         PP_STAMP();
         __syncthreads();                                  // staging tiles read back: the next operand image may overwrite them
         PP_STAMP();                                       // (WG: and the a(u) tile is complete)
@@ -544,7 +572,13 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
             PP_STAMP();
             __syncthreads();                              // image + a(u) tile free for the next tile
         }
+    };
+    // the first tile is peeled when the epilogue accumulates forward statistics: `first` as a run-time flag cost 40 selects per tile
+    int tile0 = t_beg;
+    if constexpr (!BWD) {
+        if (want_stats && tile0 < t_end) do_tile(tile0++, std::true_type{});
     }
+    for (int tile = tile0; tile < t_end; ++tile) do_tile(tile, std::false_type{});
 
     // ---- WG: weight / bias gradient partial sums of this block -> its slab ----
     if (WG && wg) {
@@ -597,7 +631,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     if (want_stats) {
         float* rec = reinterpret_cast<float*>(sS + wave * (32 * LDST));      // [64 lanes][17]: f1[8] f2[8] nrow
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { rec[lane * 17 + e] = f1[e]; rec[lane * 17 + 8 + e] = f2[e]; }
+        for (int e = 0; e < 8; ++e) { rec[lane * 17 + e] = F1[e >> 1][e & 1]; rec[lane * 17 + 8 + e] = F2[e >> 1][e & 1]; }
         rec[lane * 17 + 16] = (float)nrow;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int cv4 = (lane >> 3) & 3, ce = lane & 7;                     // lanes 0..31: channel 8 cv4 + ce of the wave's 32
@@ -610,7 +644,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         // common shift of this channel (every lane of the chunk holds the same one; lane cv4 is one of them)
         float csv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csv[e] = BWD ? 0.f : cshift[e];
+        for (int e = 0; e < 8; ++e) csv[e] = BWD ? 0.f : CS[e >> 1][e & 1];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // all reads of `rec` done before it is reused
         float* shf = rec;                                                    // [4 chunks][8]
         if ((lane >> 2) == 0) {

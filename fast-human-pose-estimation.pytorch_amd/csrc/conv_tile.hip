@@ -83,6 +83,10 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FPD_TILE_TIMING
+    if (tid == 0) fpd_tile_ns = 0;
+#endif
+    TILE_STAMP();
     const int H = a.H, W = a.W, C = a.C, K = a.K, R = a.R, pad = a.pad;
     const int M = a.N * H * W, GR = a.N * H;     // pixels, flattened (n,h) rows
     const int nrows = geo.nrows, hrows = nrows + R - 1, WP = W + R - 1;
@@ -256,6 +260,7 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
                     if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(sB + (t3 * 3 + u) * BNT * LD + b_loff[i]) = rw[u][i];
         }
     }
+    TILE_STAMP();                        // 1: first loads requested
     // ---- one-time LDS initialisation: zero border columns + zero pixels; BN tables ----
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -266,7 +271,9 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
             *reinterpret_cast<uint4*>(sH + px * LD + cv) = z;
         }
     }
+    TILE_STAMP();                        // 2: zero fill
     bn_fill(a.bn, C, (double)M, s_scale, s_shift);
+    TILE_STAMP();                        // 3: BN tables
     if (FOLD && fold) {
         // dy = gamma*is*(g - m1 - xhat*m2), xhat = (u - mu)*is  ==  A g + B u + D   (coefficients formed in fp64);
         // the upper half of the block does it while the lower half fills the epilogue tables
@@ -289,7 +296,9 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
             }
         }
     }
+    TILE_STAMP();                        // 4: fold tables
     conv_epi_tables<BNT>(a, n0, M, s_epi);
+    TILE_STAMP();                        // 5: epilogue tables
 
     if constexpr (ALLW) {
         __syncthreads();                 // tables / zero fill visible to halo_store
@@ -306,9 +315,12 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
         const int c0 = ch * BK;
         const bool more = ch + 1 < nchunk;
         __syncthreads();                 // previous chunk fully consumed (and, first time, tables/zero fill visible)
+        TILE_STAMP();                    // per chunk: barrier | staged | barrier | taps
         halo_store(c0);
         b_store(0);
+        TILE_STAMP();
         __syncthreads();
+        TILE_STAMP();
         if (more) halo_load(c0 + BK);    // in flight during all taps of this chunk
         if (RS > 1) b_load(1, c0); else if (more) b_load(0, c0 + BK);
         int r = 0, s = 0;
@@ -322,6 +334,7 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
             }
             if (++s == R) { s = 0; ++r; }
         }
+        TILE_STAMP();
     }
     }
     const int Mlim = min(M, m0 + TPX);   // rows of the 128-row MFMA tile beyond the tile's pixels belong to the next tile
@@ -331,6 +344,20 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
         __syncthreads();                 // every wave is done reading the tile region before s_red (aliased) is written
         conv_epilogue<T, TN>(a, acc, m0 + wave * 32, n0, Mlim, s_epi, s_red);
     }
+#ifdef FPD_TILE_TIMING
+    TILE_STAMP();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TILE_STAMP();                        // every memory operation of thread 0 has returned
+    __syncthreads();
+    if (tid == 0 && bx == 0 && by == 0) {
+        // entry | loads requested | zero fill | BN tables | fold tables | epi tables | per chunk: barrier, staged, barrier, taps |
+        // epilogue: barrier, staged+barrier, rows stored, [stats shuffled+barrier, barrier, atomics issued] | end | memory drained
+        printf("conv_tile R=%d C=%d K=%d HxW=%dx%d TN=%d BK=%d allw=%d fold=%d epi=%d bn=%d blocks=%dx%d:", R, C, K, H, W, TN, BK, (int)ALLW, (int)fold,
+               a.epi, a.bn.mode, (int)gridDim.x, (int)gridDim.y);
+        for (int q = 1; q < fpd_tile_ns; ++q) printf(" %lld", fpd_tile_stamp[q] - fpd_tile_stamp[0]);
+        printf("\n");
+    }
+#endif
 }
 
 template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
