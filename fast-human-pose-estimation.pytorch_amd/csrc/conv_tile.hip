@@ -136,22 +136,26 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     const int WV = W * VPR;
     uint4 rh[NVH], ru[FOLD ? NVH : 1];           // ru: the same vectors of u (fold)
     unsigned hmask = 0;
+    // Branch-free: every thread issues its requests back to back from clamped addresses (a row outside the tensor re-reads the
+    // nearest one, a thread past the last vector re-reads the last one) and the staging pass zeroes / skips them by hmask /
+    // v < nvtot.  With the loads under per-vector conditions the compiler funnelled them through one temporary and waited
+    // for each pair (FOLD variants: s_waitcnt vmcnt(0) after every second vector = four exposed memory latencies, r04 stamps).
+    const T* __restrict__ fxs = (FOLD && fold) ? fx : x;
+    const int nvh = (nvtot + 255) >> 8;          // vectors per thread (block-uniform)
     auto halo_load = [&](int c0) {
         hmask = 0;
 #pragma unroll
         for (int i = 0; i < NVH; ++i) {
-            const int v = tid + i * 256;
-            rh[i] = make_uint4(0, 0, 0, 0);
-            if (v < nvtot) {
+            if (i < nvh) {
+                const int v = min(tid + i * 256, nvtot - 1);
                 const int hr = qdiv(v, geo.mWV);
                 const int rem = v - hr * WV;
                 const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
                 const int g = g0 - pad + hr;
-                if ((unsigned)g < (unsigned)GR) {
-                    rh[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(g * W + j) * C + c0 + cv));
-                    if (FOLD && fold) ru[i] = *reinterpret_cast<const uint4*>(fx + ((size_t)(g * W + j) * C + c0 + cv));
-                    hmask |= 1u << i;
-                }
+                const size_t off = (size_t)(min(max(g, 0), GR - 1) * W + j) * C + c0 + cv;
+                rh[i] = *reinterpret_cast<const uint4*>(x + off);
+                if constexpr (FOLD) ru[i] = *reinterpret_cast<const uint4*>(fxs + off);
+                hmask |= ((unsigned)g < (unsigned)GR) ? (1u << i) : 0u;
             }
         }
     };
@@ -197,8 +201,8 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[e], psh[e]), relu_lo);
                     val = DT<T>::pack(f);
-                    if (!((hmask >> i) & 1u)) val = make_uint4(0, 0, 0, 0);      // rows outside the tensor stay exactly zero
                 }
+                if (!((hmask >> i) & 1u)) val = make_uint4(0, 0, 0, 0);          // rows outside the tensor stay exactly zero
                 *reinterpret_cast<uint4*>(sH + (hr * WP + j + pad) * LD + cvh) = val;
             }
         }
@@ -241,23 +245,38 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     // the first loads of the block go out before anything else (tables, zero fill and their fp64 arithmetic run under them)
     halo_load(0);
     if constexpr (!ALLW) b_load(0, 0);
+    constexpr bool W9 = ALLW && NVB == 1;        // 9 vectors per thread (TN = 1); 18 (TN = 2) cost the fourth block per CU
+    uint4 rw9[W9 ? 9 : 1][NVB];
     if constexpr (ALLW) {
-        // nine weight tiles [BNT][BK] -> LDS buffers 0..8, three taps in flight at a time; then the halo; ONE barrier; 9 taps
+        // nine weight tiles [BNT][BK] -> LDS buffers 0..8; then the halo; ONE barrier; 9 taps.  W9 (TN = 1: nine vectors per thread): all
+        // nine are requested here and stored behind the table arithmetic below -- one memory latency, shared with the tables'
+        // own loads (the stamps of r04 showed the three rounds of three as 3 x ~1.7 k cycles in front of everything else on
+        // launches that are pure latency); three taps at a time otherwise
+        if constexpr (W9) {
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            uint4 rw[3][NVB];
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
+            for (int u = 0; u < 9; ++u)
 #pragma unroll
                 for (int i = 0; i < NVB; ++i) {
-                    rw[u][i] = make_uint4(0, 0, 0, 0);
-                    if (b_ok[i]) rw[u][i] = *reinterpret_cast<const uint4*>(w + (b_goff[i] + (t3 * 3 + u) * C));
+                    rw9[u][i] = make_uint4(0, 0, 0, 0);
+                    if (b_ok[i]) rw9[u][i] = *reinterpret_cast<const uint4*>(w + (b_goff[i] + u * C));
                 }
+        } else {
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
+            for (int t3 = 0; t3 < 3; ++t3) {
+                uint4 rw[3][NVB];
 #pragma unroll
-                for (int i = 0; i < NVB; ++i)
-                    if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(sB + (t3 * 3 + u) * BNT * LD + b_loff[i]) = rw[u][i];
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int i = 0; i < NVB; ++i) {
+                        rw[u][i] = make_uint4(0, 0, 0, 0);
+                        if (b_ok[i]) rw[u][i] = *reinterpret_cast<const uint4*>(w + (b_goff[i] + (t3 * 3 + u) * C));
+                    }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int i = 0; i < NVB; ++i)
+                        if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(sB + (t3 * 3 + u) * BNT * LD + b_loff[i]) = rw[u][i];
+            }
         }
     }
     TILE_STAMP();                        // 1: first loads requested
@@ -301,6 +320,13 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
     TILE_STAMP();                        // 5: epilogue tables
 
     if constexpr (ALLW) {
+        if constexpr (W9) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+#pragma unroll
+                for (int i = 0; i < NVB; ++i)
+                    if (tid + i * 256 < NVB_TOT) *reinterpret_cast<uint4*>(sB + u * BNT * LD + b_loff[i]) = rw9[u][i];
+        }
         __syncthreads();                 // tables / zero fill visible to halo_store
         halo_store(0);
         __syncthreads();
@@ -360,8 +386,14 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
 #endif
 }
 
+// Waves per SIMD the register allocation must leave room for (= blocks per CU: a block is one wave per SIMD).  The variants
+// that fit 128 registers are held there -- the launches of a thousand blocks (student head 1x1 128->16 at 64x64) lose a quarter
+// of their throughput with three blocks per CU instead of four (r04: 13.7 -> 17.8 us when the count crept to 130).
+template <int TN, bool ALLW, bool FOLD>
+constexpr int tile_waves() { return (!FOLD && (TN == 1 || (TN == 2 && ALLW))) ? 4 : 2; }
+
 template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo) {
+__global__ __launch_bounds__(256, (tile_waves<TN, ALLW, FOLD>())) void conv_tile_kernel(const fpd_conv_t a, const TileGeo geo) {
     conv_tile_body<T, TN, BK, ALLW, FOLD>(a, geo, blockIdx.x, blockIdx.y);
 }
 
@@ -369,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const fpd_conv_t a, c
 // the rest to `b` (block-uniform choice; the descriptors live in kernel-argument memory).  Used for the two parallel
 // bottlenecks of an hourglass level (up-branch at full, low-branch at half resolution): one launch latency for both.
 template <typename T, int TN, int BK, bool ALLW, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const TileGeo logWa,
+__global__ __launch_bounds__(256, (tile_waves<TN, ALLW, FOLD>())) void conv_tile_pair_kernel(const fpd_conv_t a, const fpd_conv_t b, const TileGeo logWa,
                                                                 const TileGeo logWb, const int nbx_a) {
     // `b` (the half-resolution, shorter job) gets the FIRST block indices: its blocks are dispatched up front and the
     // launch ends with a's normal tail instead of a's tail followed by b's
@@ -413,9 +445,9 @@ int launch_tile_v(const fpd_conv_t& a, hipStream_t st) {
     const size_t epi = std::max((size_t)128 * (32 * TN + 4) * sizeof(float), (size_t)4 * 32 * TN * 2 * sizeof(double));
     const size_t lds = (size_t)(2 * a.C + 4 * 32 * TN + (a.epi == FPD_EPI_BNRELU_BWD ? 3 * a.C : 0)) * sizeof(float) + std::max(tile_lds<T, TN, BK, ALLW>(a), epi);
     if (lds > LDS_MAX) return 1;
+    dim3 grid(tiles_of(a), cdiv(a.K, 32 * TN));
     static LdsAttr configured;        // per device, set once (thread-safe: common.h)
     if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_kernel<T, TN, BK, ALLW>), lds)) return rc_;
-    dim3 grid(tiles_of(a), cdiv(a.K, 32 * TN));
     if constexpr (TN <= 2) {
         if (a.fold_x != nullptr) {
             static LdsAttr configured_f;        // per device, set once (thread-safe: common.h)
@@ -480,10 +512,10 @@ int launch_pair_v(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st) {
     const size_t lds = (size_t)((bwd ? 5 : 2) * std::max(a.C, b.C) + 4 * 32 * TN) * sizeof(float) +
                        std::max({tile_lds<T, TN, BK, ALLW>(a), tile_lds<T, TN, BK, ALLW>(b), epi});
     if (lds > LDS_MAX) return 1;
-    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
-    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>), lds)) return rc_;
     const int nbx_a = tiles_of(a), nbx_b = tiles_of(b);
     dim3 grid(nbx_a + nbx_b, cdiv(a.K, 32 * TN));
+    static LdsAttr configured;        // per device, set once (thread-safe: common.h)
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&conv_tile_pair_kernel<T, TN, BK, ALLW>), lds)) return rc_;
     if constexpr (TN <= 2) {
         if (a.fold_x != nullptr || b.fold_x != nullptr) {
             static LdsAttr configured_f;        // per device, set once (thread-safe: common.h)
