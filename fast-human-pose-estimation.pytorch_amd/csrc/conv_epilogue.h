@@ -98,20 +98,20 @@ __device__ __forceinline__ void conv_epi_tables(const fpd_conv_t& a, const int n
 // that (cross-thread, cross-block) is fp64.  The BN-backward sums {dz, dz*xhat} have no such cancellation and are
 // accumulated in fp32 per thread, fp64 beyond.
 //   stage: >= 128*(32*TN+4) floats, 16-byte aligned; s_red: >= 4*32*TN*2 doubles (may alias stage)
-// A wave reads back exactly the 32 rows it staged (rows wave*32 + lane / CVN + i * RSTEP), so nothing between the staging
-// stores and the row loop crosses waves: one block barrier (tile region free) in front of the epilogue, none inside it up to
-// the statistics.  (r04, measured and dropped: a staging tile of its own, i.e. no barrier at all -- no gain, the launches this
-// would matter for are bound by instruction issue of one wave per SIMD, not by barriers; statistics added per wave instead
-// of through the block-level reduction -- slower at every size: 16 limb splits per lane cost ~420 fp64 instructions, and
-// from 128 blocks on the same-address atomics serialise in the L2.)
+// (r04, measured and dropped: a wave reading back only the rows it staged -- one block barrier less, no measurable gain, and the
+// regrouped fp32 partial sums of the statistics move every bit-level regression pin of the repo (the trained-pair pin, the golden
+// training curve); a staging tile of its own, i.e. no barrier at all in front of the staging stores -- no gain: the launches this
+// would matter for are bound by instruction issue of one wave per SIMD, not by barriers; statistics added per wave instead of
+// through the block-level reduction -- slower at every size: 16 limb splits per lane cost ~420 fp64 instructions, and from 128
+// blocks on the same-address atomics serialise in the L2.)
 template <typename T, int TN>
 __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32x16* acc, const int m0, const int n0,
                                                   const int M, const float* s_epi, float* stage, double* s_red) {
     constexpr int VEC = DT<T>::VEC;
-    constexpr int BNT = 32 * TN, LDST = BNT + 4, CVN = BNT / VEC, RSTEP = 64 / CVN;
+    constexpr int BNT = 32 * TN, LDST = BNT + 4, CVN = BNT / VEC, RSTEP = 256 / CVN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K;
-    const int cv = lane % CVN, row0 = wave * 32 + lane / CVN;
+    const int cv = tid % CVN, row0 = tid / CVN;
     const int k0 = n0 + cv * VEC;
     const bool kok = k0 < K;
     T* __restrict__ y = reinterpret_cast<T*>(a.y);
@@ -137,7 +137,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
     // The rows a thread owns are processed in groups of G: the residual / epi_x vectors of a whole group are requested
     // together (one memory latency per group instead of one per row -- these launches are latency-bound), and the first
     // group's requests go out BEFORE the accumulators travel through the LDS staging tile.
-    constexpr int NR = 32 / RSTEP, G = NR < 4 ? NR : 4, NG = NR / G;
+    constexpr int NR = 128 / RSTEP, G = NR < 4 ? NR : 4, NG = NR / G;
     static_assert(NR % G == 0, "row groups");
     uint4 rres[G], rex[G];
     auto request = [&](int g) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const fpd_conv_t& a, const f32
             const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * rhalf;
             stage[row * LDST + tn * 32 + col_l] = acc[tn][i];
         }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's staging stores are in the LDS (it reads back only its own rows)
+    __syncthreads();
     TILE_STAMP();
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
