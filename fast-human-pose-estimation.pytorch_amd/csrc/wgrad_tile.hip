@@ -412,8 +412,25 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const fpd_wreduce_entry_t*
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(e.dw + 4 * i);
         const float* p = e.partial + 4 * i;
-#pragma unroll 4
-        for (int b = 0; b < e.count; ++b) {
+        // The slabs are ADDED one after the other in index order (the result must not depend on the launch geometry of this
+        // kernel), but REQUESTED sixteen at a time: with four in flight a thread paid count / 4 memory latencies in a row
+        // (128 slabs: 29 us for a few hundred KB, r04 trace).
+        int b = 0;
+        for (; b + 16 <= e.count; b += 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(b + u) * e.stride);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+        }
+        for (; b + 4 <= e.count; b += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(b + u) * e.stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+        }
+        for (; b < e.count; ++b) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)b * e.stride);
             acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
         }
