@@ -22,6 +22,9 @@ import re
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import trace_align
+
 out = sys.argv[1]
 PFX = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 SUB = sys.argv[3] if len(sys.argv) > 3 else ''      # 'hrnet_': the passes over `bench.py --config hrnet` (directories hrnet_stats, hrnet_step_*)
@@ -32,23 +35,12 @@ def short(n):
     return n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:60]
 
 
-def base_name(expr):
-    """'(conv_pp_kernel<R, C, KH, BWD, WG>)' / 'adam_kernel' -> 'conv_pp_kernel' (what the trace's kernel name must contain)"""
-    return re.sub(r'[(<].*', '', expr.strip().lstrip('(')).strip()
-
-
 def load_log(sub):
     """[(kernel base name, grid blocks, block threads, op index, shape tag)] in host order, or None."""
     path = os.path.join(out, sub, 'launch.log')
     if not os.path.exists(path):
         return None
-    rows = []
-    for line in open(path):
-        f = line.rstrip('\n').split('\t')
-        if len(f) < 4:
-            continue
-        rows.append((base_name(f[0]), int(f[1]), int(f[2]), f[3], f[4] if len(f) > 4 else ''))
-    return rows
+    return trace_align.parse_log(open(path))
 
 
 def trace(sub):
@@ -64,16 +56,9 @@ def shapes_by_dispatch(sub, rows):
     if not log:
         print('%s: no launch log -- rows are keyed on (kernel, grid) only' % sub)
         return {}
-    names = set(l[0] for l in log)
-    ours = [r for r in sorted(rows, key=lambda r: int(r['Dispatch_Id'])) if any(n in r['Kernel_Name'] for n in names)]
-    tags, bad = {}, 0
-    if len(ours) != len(log):
-        print('%s: %d trace rows of library kernels vs %d logged launches -- aligning the common prefix' % (sub, len(ours), len(log)))
-    for r, l in zip(ours, log):
-        if l[0] not in r['Kernel_Name']:
-            bad += 1
-            continue
-        tags[r['Dispatch_Id']] = l[4]
+    tags, bad, n_trace, n_log = trace_align.align(log, rows)
+    if n_trace != n_log:
+        print('%s: %d trace rows of library kernels vs %d logged launches -- aligning the common prefix' % (sub, n_trace, n_log))
     print('%s: %d launches keyed on their shape, %d name mismatches' % (sub, len(tags), bad))
     return tags
 

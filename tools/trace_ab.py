@@ -4,14 +4,13 @@
 Runs `bench.py --steps 12 --warmup 4` under rocprofv3 --kernel-trace once per library (launch log next to the trace), keys the trace rows on
 the launch log's shape tags (as tools/profile_summarize.py does) and prints average microseconds per launch side by side, largest
 difference per step first."""
-import collections, csv, glob, os, re, subprocess, sys
+import collections, csv, glob, os, subprocess, sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import trace_align
 
 out, libs, pat = os.path.abspath(sys.argv[1]), sys.argv[2:4], (sys.argv[4] if len(sys.argv) > 4 else '')
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def base_name(expr):
-    return re.sub(r'[(<].*', '', expr.strip().lstrip('(')).strip()
 
 
 def run(tag, lib):
@@ -26,15 +25,16 @@ def run(tag, lib):
                     '--no-cpu-baseline', '--no-parity', '--steps', '12', '--warmup', '4'], cwd='/tmp', env=env,
                    stdout=open(d + '.log', 'w'), stderr=subprocess.STDOUT)
     rows = [r for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True) for r in csv.DictReader(open(f))]
-    log = [l.rstrip('\n').split('\t') for l in open(os.path.join(d, 'launch.log'))]
-    log = [(base_name(f[0]), f[4] if len(f) > 4 else '') for f in log if len(f) >= 4]
-    names = set(l[0] for l in log)
-    ours = [r for r in sorted(rows, key=lambda r: int(r['Dispatch_Id'])) if any(n in r['Kernel_Name'] for n in names)]
+    log = trace_align.parse_log(open(os.path.join(d, 'launch.log')))
+    tags, bad, n_trace, n_log = trace_align.align(log, rows)
+    if bad or n_trace != n_log:
+        print('%s: %d trace rows vs %d logged launches, %d name mismatches' % (tag, n_trace, n_log, bad))
+    ours = trace_align.library_rows(rows, set(l[0] for l in log))
     steps = sum(1 for r in ours if 'adam_kernel' in r['Kernel_Name'])
     agg = collections.defaultdict(list)
     for r, l in zip(ours, log):
-        if l[0] in r['Kernel_Name']:
-            agg[(l[0], l[1])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        if r['Dispatch_Id'] in tags:
+            agg[(l[0], l[4])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     return agg, steps
 
 
