@@ -279,3 +279,11 @@ def test_launch_log_keys_every_kernel_launch_on_its_plan_op_and_shape(tmp_path):
     # plan ops and logged launches agree: memsets are not kernels of the library, adam is two launches (update + tick)
     n_ops = int(out.stdout.split('LAUNCHES')[1].split()[0])
     assert abs(len(lines) - n_ops) <= 16, (len(lines), n_ops)
+
+
+def test_graft_entry_smoke_runs_in_a_fresh_process():
+    """`__graft_entry__.smoke()` is what the driver runs on the box before the bench: one fused step of the 'tiny' case on cuda:0
+    against the goldens and the fp64 oracle.  Run the way the driver does -- a fresh interpreter started at the repo root."""
+    p = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.smoke()'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert 'smoke ok' in p.stdout, p.stdout[-2000:]
