@@ -108,7 +108,8 @@ static int validate_conv_dims(int N, int H, int W, int C, int K, int R, int S, i
 extern "C" {
 
 const char* fpd_last_error(void) { return g_err; }
-int fpd_abi_version(void) { return 1; }
+int fpd_abi_version(void) { return FPD_ABI_VERSION; }
+int64_t fpd_stats_words(int32_t channels) { return FPD_STATS_WORDS(channels); }
 int fpd_set_backend(int32_t backend) {
     const int prev = g_fpd_backend;
     if (backend == FPD_BACKEND_MFMA || backend == FPD_BACKEND_NAIVE || backend == FPD_BACKEND_MFMA_GENERIC) g_fpd_backend = backend;

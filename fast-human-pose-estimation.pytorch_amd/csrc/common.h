@@ -110,11 +110,15 @@ struct DT<bf16_t> {
 // ---- exact statistics (include/fpd_amd.h, fpd_stat_t): a value travels as two 64-bit integer limbs ----------------
 // Integer addition is associative, so the sums do not depend on the order in which blocks (device atomics) or threads
 // (LDS atomics) contribute: bit-repeatable statistics at the cost of an fp64 atomic pair (tools/probes/pdl_probe.hip).
-#define FPD_STAT_HI_SCALE 256.0                       // hi limb: units of 2^-8
+// Headroom: the residual a contribution leaves in its lo limb is <= 2^-21, i.e. |lo| <= 2^39 in units of
+// 2^-60, so 2^24 = 16.7 M contributions of ANY sign pattern fit the 63 bits of a limb sum (the largest producer of the hot
+// path, a capped elementwise grid, adds 512 blocks x 256 threads = 2^17 per channel).  The first encoding of round 4
+// (hi in units of 2^-8, |lo| <= 2^51) wrapped after 4 096 worst-case addends.
+#define FPD_STAT_HI_SCALE 1048576.0                   // hi limb: units of 2^-20
 #define FPD_STAT_LO_SCALE 1152921504606846976.0       // lo limb: units of 2^-60
 struct StatLimbs { long long hi, lo; };
 __device__ __forceinline__ StatLimbs stat_split(double v) {
-    const double lim = 18014398509481984.0;           // 2^54: beyond it (or NaN) the network has diverged; stay finite and huge
+    const double lim = 4398046511104.0;               // 2^42: beyond it (or NaN) the network has diverged; stay finite and huge
     v = (v == v) ? fmin(fmax(v, -lim), lim) : lim;
     StatLimbs s;
     s.hi = __double2ll_rn(v * FPD_STAT_HI_SCALE);

@@ -26,7 +26,7 @@ def act_torch_dtype(dtype):
     return torch.bfloat16 if dtype == R.BF16 else torch.float32
 
 
-_STAT_HI, _STAT_LO = 256.0, float(2 ** 60)      # include/fpd_amd.h fpd_stat_t: value = hi * 2^-8 + lo * 2^-60
+_STAT_HI, _STAT_LO = float(2 ** 20), float(2 ** 60)      # include/fpd_amd.h fpd_stat_t: value = hi * 2^-20 + lo * 2^-60
 
 
 class Arenas:

@@ -174,6 +174,8 @@ _STRUCTS = {'fpd_bn_t': BnT, 'fpd_conv_t': ConvT, 'fpd_wgrad_t': WgradT, 'fpd_st
             'fpd_warp_src_t': WarpSrcT, 'fpd_warp_t': WarpT}
 
 # every symbol include/fpd_amd.h declares: name -> (restype, argtypes)
+ABI_VERSION = 2      # include/fpd_amd.h FPD_ABI_VERSION
+
 SYMBOLS = {
     'fpd_conv_forward': (C.c_int, [C.POINTER(ConvT), _vp]),
     'fpd_conv_forward_pair': (C.c_int, [C.POINTER(ConvPairT), _vp]),
@@ -227,6 +229,7 @@ SYMBOLS = {
     'fpd_set_option': (C.c_int, [C.c_char_p, _i32]),
     'fpd_abi_sizeof': (C.c_int, [C.c_char_p]),
     'fpd_abi_version': (C.c_int, []),
+    'fpd_stats_words': (C.c_int64, [C.c_int32]),
     'fpd_event_create': (_vp, []),
     'fpd_event_record': (C.c_int, [_vp, _vp]),
     'fpd_event_elapsed_ms': (C.c_float, [_vp, _vp]),
@@ -261,6 +264,8 @@ def lib():
         fn = getattr(l, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if l.fpd_abi_version() != ABI_VERSION:       # buffer encodings sizeof cannot see (include/fpd_amd.h FPD_ABI_VERSION)
+        raise FpdError('ABI version mismatch: library %d, python host %d' % (l.fpd_abi_version(), ABI_VERSION))
     for name, st in _STRUCTS.items():
         got = l.fpd_abi_sizeof(name.encode())
         if got != C.sizeof(st):

@@ -33,10 +33,13 @@ enum { FPD_F32 = 0, FPD_BF16 = 1 };
  * into ONE address serialise at ~20 ns per atomic); consumers sum the replicas.
  * The sums are EXACT and therefore independent of the order in which the blocks' contributions arrive (a training step
  * is bit-repeatable): a block's fp64 partial v is added as two 64-bit INTEGER limbs
- *     hi = rint(v * 2^8)                      units of 2^-8   (|v| clamped to 2^54)
- *     lo = rint((v - hi * 2^-8) * 2^60)       units of 2^-60  (|lo| <= 2^51)
+ *     hi = rint(v * 2^20)                     units of 2^-20  (|v| clamped to 2^42)
+ *     lo = rint((v - hi * 2^-20) * 2^60)      units of 2^-60  (|lo| <= 2^39)
  * with integer atomics (associative, unlike floating-point ones; measured on MI355X: same cost as an fp64 atomic pair),
- * value = hi * 2^-8 + lo * 2^-60.  Layout of one buffer over C channels: fpd_stat_t [R][2 sums][2 limbs: hi, lo][C]
+ * value = hi * 2^-20 + lo * 2^-60.  BOUND: a limb sum is a 64-bit integer, so one (replica, sum, channel) takes up to
+ * 2^24 contributions whatever their signs (|lo| <= 2^39 each) and a total of magnitude < 2^42; both are checked nowhere
+ * at run time -- the producers of this library add at most 2^17 contributions per channel (ABI version 2; version 1 used
+ * hi units of 2^-8, which wrapped after 4 096 worst-case addends).  Layout of one buffer over C channels: fpd_stat_t [R][2 sums][2 limbs: hi, lo][C]
  * (FPD_STATS_WORDS(C) 64-bit words); the caller zeroes it (all-zero bytes = all-zero sums). */
 #ifndef FPD_STATS_REPLICAS
 #define FPD_STATS_REPLICAS 4
@@ -529,7 +532,13 @@ int fpd_set_backend(int32_t backend);         /* FPD_BACKEND_*; returns previous
  * previous value (>= 0; 0 for "wgrad_tile_only"), negative = unknown option. */
 int fpd_set_option(const char* name, int32_t value);
 int fpd_abi_sizeof(const char* struct_name);  /* sizeof of a struct above, -1 if unknown */
+/* Version of everything sizeof cannot see (buffer encodings and sizes).  History: 1 = statistics as fp64 [R][2][C] (rounds 1-3)
+ * and, mistakenly unchanged, the first integer-limb encoding of round 4; 2 = fpd_stat_t limbs [R][2][2][C] with hi in units of
+ * 2^-20 (twice the bytes of version 1's buffers: a host built against version 1 must not run).  Hosts assert
+ * fpd_abi_version() == FPD_ABI_VERSION and size statistics buffers with fpd_stats_words(). */
+#define FPD_ABI_VERSION 2
 int fpd_abi_version(void);
+int64_t fpd_stats_words(int32_t channels);    /* 64-bit words of one statistics buffer over `channels` = FPD_STATS_WORDS(channels) */
 /* in-stream timing helpers (HIP events on `stream`): returns elapsed ms of [start,stop) */
 void* fpd_event_create(void);
 int fpd_event_record(void* ev, fpd_stream_t stream);

@@ -39,7 +39,8 @@ def test_struct_sizes_match(runtime):
     for name, st in runtime._STRUCTS.items():
         assert runtime.lib().fpd_abi_sizeof(name.encode()) == ctypes.sizeof(st), name
     assert runtime.lib().fpd_abi_sizeof(b'nope') == -1
-    assert runtime.lib().fpd_abi_version() == 1
+    assert runtime.lib().fpd_abi_version() == runtime.ABI_VERSION == 2
+    assert runtime.lib().fpd_stats_words(64) == 4 * 4 * 64
 
 
 def test_validation_errors_without_device(runtime):
@@ -163,7 +164,7 @@ def test_host_side_dispatch_predicates_of_round_3_without_a_device(runtime):
 
 def test_exact_statistics_encoding_round_trip_and_order_independence():
     """include/fpd_amd.h fpd_stat_t as the host sees it (executor.Arenas.stats_write / stats_read on CPU tensors): a value
-    travels as two 64-bit integer limbs, hi = rint(v * 2^8) and lo = rint((v - hi * 2^-8) * 2^60); the split is exact to
+    travels as two 64-bit integer limbs, hi = rint(v * 2^20) and lo = rint((v - hi * 2^-20) * 2^60); the split is exact to
     2^-61 over the whole range a BatchNorm sum can take, and -- the point of the format -- integer limb sums do not depend
     on the order of the addends, where fp64 sums of the same addends do."""
     import numpy as np
@@ -176,7 +177,7 @@ def test_exact_statistics_encoding_round_trip_and_order_independence():
     assert A.tensor('stats').dtype == torch.int64 and A.tensor('stats').numel() == 2 * (R * 2 * C + 64)
     assert A.ptr(buf) - A.tensor('stats').data_ptr() == 16 * 16          # two 8-byte limbs per logical element
     rng = np.random.RandomState(0)
-    vals = torch.from_numpy(np.concatenate([rng.standard_normal(R * C) * 10.0 ** rng.uniform(-12, 12, R * C),
+    vals = torch.from_numpy(np.concatenate([rng.standard_normal(R * C) * 10.0 ** rng.uniform(-12, 11, R * C),
                                             np.array([0.0, 1.0, -1.0, 2.0 ** -40, -2.0 ** 40, 1e-15, 123456.789, -0.1] * (R * C // 8))]
                                            ).reshape(R, 2, C))
     A.stats_write(buf, vals)
@@ -184,11 +185,11 @@ def test_exact_statistics_encoding_round_trip_and_order_independence():
     err = (back - vals).abs()
     assert float(err.max()) <= 2.0 ** -60 and float((err / vals.abs().clamp_min(1e-300))[vals.abs() > 1e-9].max()) < 1e-9
     raw = A.view(buf)
-    assert raw.shape == (R, 2, 2, C) and int(raw[:, :, 1, :].abs().max()) <= 2 ** 51      # |lo| <= 2^51: 2048 addends fit 63 bits
+    assert raw.shape == (R, 2, 2, C) and int(raw[:, :, 1, :].abs().max()) <= 2 ** 39      # |lo| <= 2^39: 2^24 addends fit 63 bits
     # order independence: sum 2048 "block partials" as limbs in two different orders -> identical limbs; as doubles -> not
     parts = rng.standard_normal(2048) * 10.0 ** rng.uniform(-6, 6, 2048)
-    hi = np.rint(parts * 256.0).astype(np.int64)
-    lo = np.rint((parts - hi / 256.0) * 2.0 ** 60).astype(np.int64)
+    hi = np.rint(parts * 2.0 ** 20).astype(np.int64)
+    lo = np.rint((parts - hi / 2.0 ** 20) * 2.0 ** 60).astype(np.int64)
     perm = rng.permutation(2048)
     assert hi.sum() == hi[perm].sum() and lo.sum() == lo[perm].sum()
     s1 = s2 = 0.0
@@ -197,5 +198,15 @@ def test_exact_statistics_encoding_round_trip_and_order_independence():
     for v in parts[perm]:
         s2 += v
     assert s1 != s2                                          # what the fp64 atomics of rounds 1-3 did to the last bits
-    exact = float(hi.sum()) / 256.0 + float(lo.sum()) / 2.0 ** 60
+    exact = float(hi.sum()) / 2.0 ** 20 + float(lo.sum()) / 2.0 ** 60
     assert abs(exact - s1) <= 1e-9 * np.abs(parts).sum()
+    # headroom: 32 768 same-sign contributions below 2^-9 -- the per-thread sums of y^2 of a channel with
+    # rms 0.009 -- wrapped the lo limb of the first encoding (|lo| <= 2^51: 4 096 worst-case addends); |lo| <= 2^39 leaves 2^24
+    small = np.full(32768, 1.3e-3) * (1.0 + 1e-3 * rng.standard_normal(32768))
+    hi = np.rint(small * 2.0 ** 20).astype(np.int64)
+    lo = np.rint((small - hi / 2.0 ** 20) * 2.0 ** 60).astype(np.int64)
+    assert int(np.abs(lo).max()) <= 2 ** 39 and abs(int(lo.sum())) < 2 ** 55
+    joined = float(hi.sum()) / 2.0 ** 20 + float(lo.sum()) / 2.0 ** 60
+    assert abs(joined - small.sum()) <= 1e-12 * small.sum()
+    old_lo = np.rint((small - np.rint(small * 256.0) / 256.0) * 2.0 ** 60)      # what version 1 summed: past 2^63
+    assert float(old_lo.sum()) > 2.0 ** 63

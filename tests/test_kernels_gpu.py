@@ -645,6 +645,28 @@ def test_elementwise_ops(shape, dtype):
     bt.compare(dbt, atol=TOL[dtype]['atol'] * n, rtol=TOL[dtype]['rtol'], label='dbeta')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_statistics_limbs_have_headroom_for_many_small_addends(dtype):
+    """the exact statistics add one contribution per THREAD in the elementwise producers -- 32 768 per
+    channel at C = 32 -- and each leaves a residual below one hi unit in the lo limb.  With hi in units of 2^-8 the lo limbs of
+    sub-2^-9 contributions (sum y^2 of a channel with rms 0.009) wrapped 2^63 once they added up to 8; hi units of 2^-20 leave
+    2^24 addends.  Pooled map of 131 072 pixels per channel, sum of squares ~ 25: must match fp64 to fp32-partial accuracy."""
+    shape = (32, 128, 128, 32)
+    gen = torch.Generator().manual_seed(77)
+    bt = Bench(dtype)
+    x = bt.act(shape, 0.009 * rnd(gen, *shape) + 0.012, 'x')
+    y = bt.act((32, 64, 64, 32), None, 'y')
+    st = bt.buf('stats', (RS, 2, 32), torch.zeros(RS, 2, 32, dtype=torch.float64))
+    op = G.Op('ew', op='maxpool_fwd', dims=shape, x=x, x2=None, dy=None, add=None, y=y, out_stats=st, bstats=None,
+              dgamma=None, dbeta=None, bn=None)
+    bt.realise().run([op], 0)
+    got = bt.gpu.stats_read(st).cpu().sum(0)
+    yd = bt.gpu.view(y.buf).cpu().double()
+    want = torch.stack([yd.sum((0, 1, 2)), (yd * yd).sum((0, 1, 2))])
+    assert float(want[1].min()) > 8.0                      # the regime in which version 1 wrapped
+    assert float(((got - want).abs() / want.abs()).max()) < 1e-5, (got, want)
+
+
 def test_maxpool_bwd_ties_first_max():
     """All-equal windows: torch routes the gradient to the first element in scan order; so must we."""
     bt = Bench(0)
