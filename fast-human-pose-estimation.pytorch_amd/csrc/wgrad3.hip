@@ -1,0 +1,394 @@
+// wgrad3: weight gradient of the student's 3x3 "same" convolution (bf16, C and K multiples of 32 up to 64, 16..128-wide maps),
+//     dw[k][r][s][c] = sum_m dy[m][k] * relu(bn(x))[m + (r-1, s-1)][c] ,   dbias[k] = sum_m dy[m][k],
+// restructured in round 5 around the slab traffic that bounded wgrad_tile (128 persistent blocks, each owning the whole
+// K x C x 9 accumulator = a private 147 KB slab: 18.9 MB written and read again by the slab reduction for ONE 147 KB gradient,
+// halo rows re-fetched by strided tiles: 2.07x the algorithmic HBM bytes, 0.096 of the roofline at 64x64).
+//
+// Decomposition: the K x C plane is cut into 32 x 32 PIECES (kt, ct); a block owns one piece for ALL nine taps and walks a
+// CONTIGUOUS range of 128-pixel tiles (whole image rows).  The pieces of one range share an XCD (block b runs on XCD b % 8), so
+// the two readers of every 64-byte half row meet in that XCD's L2 and HBM sees each byte of x and dy once.  A block's
+// accumulator is 9 x 32 x 32 floats = 36 KB, and a gradient is summed from `nranges` slabs (<= 64) instead of 128:
+// 4.7-9.4 MB of slab traffic at 64x64, less below.
+//
+// Per tile a block stages 32 channels of dy (128 pixels x 64 B) and of x: the halo lives in a RING of nrows + 2 image rows in
+// LDS (row g sits in slot (g + 1) % RING), so every x row is fetched ONCE per block (BatchNorm + ReLU applied once per element on
+// the way in) -- a tile brings only its nrows new rows.  Rows are unpadded 64-byte records: the transposing read
+// ds_read_b64_tr_b16, which turns the pixel axis into the MFMA k axis (mfma_frag.h), touches four consecutive 64-byte rows per
+// half wave = all 64 banks once, conflict-free, where wgrad_tile's 144-byte rows collided two-way.  Image borders: the ring has a
+// zero column on either side of a row; a tap row outside the image reads a block of zero pixels instead (uniform select).
+// The four waves of a block split the eight 16-pixel k-steps of a tile (two each: 1 dy fragment + 9 x fragments -> 9 MFMAs, 1.1
+// fragment reads per MFMA) and keep all nine 32 x 32 accumulators; two blocks share a CU (<= 256 VGPRs, 48 KB LDS), one staging
+// while the other multiplies.  At the end the four waves' accumulators are added in a FIXED order through LDS and stored to the
+// range's slab -- no atomics: fpd_wgrad_reduce() adds the slabs in index order, identical bytes run to run.
+// Replaces autograd of nn.Conv2d (weight / bias gradient) in /root/reference/lib/models/hourglass.py:23 (conv2 of a Bottleneck).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "mfma_frag.h"
+
+namespace {
+
+constexpr int W3_BLK = 512, W3_NW = 8, W3_TP = 256, W3_CH = 32;      // threads, waves, pixels per tile, staged channels
+constexpr int W3_PIXB = W3_CH * 2;                                   // bytes of a staged pixel: 64 (an unpadded LDS row)
+constexpr int W3_ZPIX = 24;                                          // zero pixels (every fragment read of a tap row outside the image)
+constexpr int W3_RED_BYTES = W3_NW * 3 * 16 * 64 * 4;                // one pass of the final cross-wave sum: 8 waves x 3 taps = 96 KB
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 w3_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p)));
+}
+// relu(bn(.)) of two packed bf16: the scalar form's operations per element in the same order (fma in fp32, one rounding, ReLU --
+// on the rounded value: rounding is monotonic and keeps the sign) as v_pk_fma_f32 / v_cvt_pk_bf16_f32 / v_pk_max_i16
+__device__ __forceinline__ unsigned w3_bn2(unsigned w, f32x2 sc, f32x2 sh, short floor_) {
+    f32x2 v = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    v = __builtin_elementwise_fma(v, sc, sh);
+    const unsigned r = f2bf_pk(v[0], v[1]);
+    s16x2 q = __builtin_bit_cast(s16x2, r);
+    const s16x2 f = {floor_, floor_};
+    q = __builtin_elementwise_max(q, f);
+    return __builtin_bit_cast(unsigned, q);
+}
+
+// Probe build only (-DW3_TIMING): cycle stamps of thread 0 of block 0 at the phase boundaries, printed by the kernel
+#ifdef W3_TIMING
+__shared__ long long w3_stamp[64];
+__shared__ int w3_ns;
+#define W3_STAMP() do { if (threadIdx.x == 0 && blockIdx.x == 0 && w3_ns < 64) w3_stamp[w3_ns++] = clock64(); } while (0)
+#else
+#define W3_STAMP() do { } while (0)
+#endif
+
+struct W3Grid { int nrows, lgW, ring, npieces, nranges, mtiles, blocks; size_t lds; };
+
+// The tile loop is bound by INSTRUCTION ISSUE, not by memory, LDS bandwidth or the matrix pipe (r05 stamps: 340 instructions per
+// wave and 256-pixel tile against 20 MFMAs ran 2 850 cycles per tile, and neither deeper prefetch nor fewer LDS reads moved it;
+// two waves per SIMD issue about one instruction per 4 cycles between them).  So everything that is the same for every tile is a
+// running value instead of being recomputed: the LDS byte offset of each of the wave's six tap rows and of the thread's two staging
+// stores advance by a constant and wrap with one min; the image row of the wave's two k-steps likewise; global requests are a
+// scalar base + a per-thread offset computed once; scale / shift live in registers.
+__global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, const int nrows, const int lgW, const int npieces,
+                                                           const int nranges, const int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: provably uniform -> scalar unit
+    const int H = a.H, W = a.W, C = a.C, K = a.K;
+    const int GR = a.N * H;                       // flat image rows (a multiple of nrows: w3_grid)
+    const int WP = W + 2, RING = 2 * nrows + 2;
+    const unsigned RS = (unsigned)WP * W3_PIXB;   // bytes of a ring row
+    const unsigned RINGBYTES = (unsigned)RING * RS, STEP = (unsigned)nrows * RS;
+
+    // block -> (range, piece): the pieces of a range share b % 8 (= the XCD a block lands on, for speed only)
+    const int b = blockIdx.x, q = b >> 3;
+    const int piece = q % npieces, range = (q / npieces) * 8 + (b & 7);
+    if (range >= nranges) return;
+    const int cpieces = C / W3_CH;
+    const int kt = piece / cpieces, ct = piece - kt * cpieces;
+    const int k0 = kt * W3_CH, c0 = ct * W3_CH;
+    const int t_begin = (int)(((long long)range * mtiles) / nranges), t_end = (int)(((long long)(range + 1) * mtiles) / nranges);
+    const int ntl = t_end - t_begin;
+
+#ifdef W3_TIMING
+    if (threadIdx.x == 0) w3_ns = 0;
+#endif
+    W3_STAMP();                                                  // 0: entry
+    // LDS map (bytes): [0, 256) scale / shift; ring [RING][WP][64 B]; dy tiles [2][256][64 B]; zero pixels [24][64 B]
+    float* s_scale = reinterpret_cast<float*>(smem);
+    float* s_shift = s_scale + W3_CH;
+    unsigned char* sH = smem + 2 * W3_CH * sizeof(float);
+    unsigned char* sD = sH + RINGBYTES;
+    unsigned char* sZ = sD + 2 * W3_TP * W3_PIXB;
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+    const short floor_ = a.bn.relu ? (short)0 : (short)-32768;
+    const bool has_bn = a.bn.mode != FPD_BN_NONE;
+
+    const int cv8 = (tid & 3) * 8;                     // the 8 channels (of the staged 32) this thread always moves
+    const int px = tid >> 2;                           // its pixels of a tile / of a tile's new rows: px and px + 128
+    const int rn0 = px >> lgW, rn1 = (px + 128) >> lgW, js = px & (W - 1);
+    // global requests: scalar base of the tile + a per-thread element offset computed once (32-bit: a tensor of this kernel's
+    // domain has < 2^31 elements).  x rows are clamped per thread (the last tile's last new row lies one past the tensor: it lands
+    // in a ring slot only taps outside the image address, and those read the zero pixels), tiles past the end of the tensor as a
+    // whole (their data is never multiplied).
+    const unsigned xrow = (unsigned)(W * C), drow = (unsigned)(W * K);
+    const unsigned xoff = (unsigned)(js * C + c0 + cv8);
+    const unsigned doffa = (unsigned)rn0 * drow + (unsigned)(js * K + k0 + cv8), doffb = (unsigned)rn1 * drow + (unsigned)(js * K + k0 + cv8);
+    uint4 rxa, rxb, rda, rdb;                          // one tile in flight in registers (a second one is in flight in LDS)
+    auto loads = [&](int Gt) {                         // new rows Gt + 1 .. Gt + nrows of x, rows Gt .. Gt + nrows - 1 of dy
+        const int Gc = min(Gt, GR - nrows);
+        const bf16_t* dyt = dy + (size_t)Gc * drow;
+        const unsigned ra = (unsigned)min(Gc + 1 + rn0, GR - 1), rb = (unsigned)min(Gc + 1 + rn1, GR - 1);
+        rxa = *reinterpret_cast<const uint4*>(x + (ra * xrow + xoff));
+        rxb = *reinterpret_cast<const uint4*>(x + (rb * xrow + xoff));
+        rda = *reinterpret_cast<const uint4*>(dyt + doffa);
+        rdb = *reinterpret_cast<const uint4*>(dyt + doffb);
+    };
+    const int G0 = t_begin * nrows;                    // first flat row of the range
+    loads(G0);
+    // rows G0 - 1 and G0 come in directly (every later row arrives as a "new row" of some tile): 8 W vectors <= one per thread
+    const bool has_first = tid < 8 * W;
+    const int frow = min(max(G0 - 1 + rn0, 0), GR - 1);       // rn0 is 0 / 1 for those threads
+    const uint4 rfirst = *reinterpret_cast<const uint4*>(x + ((unsigned)frow * xrow + xoff));
+    BnRaw braw;
+    if (tid < W3_CH) bn_request(a.bn, c0 + tid, C, braw);
+    W3_STAMP();                                                  // 1: prologue requests issued
+    // zero what is never written: the border columns of the ring rows and the zero pixels (every ring row and dy pixel that is
+    // multiplied has been stored before)
+    for (int v = tid; v < (2 * RING + W3_ZPIX) * 4; v += W3_BLK) {
+        const int pz = v >> 2;
+        unsigned char* dst = pz < 2 * RING ? sH + (unsigned)(pz >> 1) * RS + (unsigned)(pz & 1) * (unsigned)(W + 1) * W3_PIXB
+                                            : sZ + (unsigned)(pz - 2 * RING) * W3_PIXB;
+        *reinterpret_cast<uint4*>(dst + (v & 3) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    if (tid < W3_CH) {
+        float sc = 1.f, sh = 0.f, mu, is;
+        if (has_bn) bn_resolve(braw, (double)a.N * H * W, sc, sh, mu, is);
+        s_scale[tid] = sc; s_shift[tid] = sh;
+    }
+    W3_STAMP();                                                  // 2: zero fill + BN table written
+    __syncthreads();
+    W3_STAMP();                                                  // 3: barrier
+    f32x2 psc[4], psh[4];                              // this thread's 8 channels: scale / shift pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        psc[e] = *reinterpret_cast<const f32x2*>(s_scale + cv8 + 2 * e);
+        psh[e] = *reinterpret_cast<const f32x2*>(s_shift + cv8 + 2 * e);
+    }
+    auto bn_vec = [&](const uint4 r) {
+        return make_uint4(w3_bn2(r.x, psc[0], psh[0], floor_), w3_bn2(r.y, psc[1], psh[1], floor_),
+                          w3_bn2(r.z, psc[2], psh[2], floor_), w3_bn2(r.w, psc[3], psh[3], floor_));
+    };
+
+    // slot(row) = (row + 1) % RING.  Running ring offsets (bytes from sH, multiples of RS, kept in [0, RINGBYTES) by
+    // v = min(v, v - RINGBYTES) on unsigned values): wsa / wsb = where this thread's two new-row vectors of the NEXT tile go.
+    const unsigned sG0 = (unsigned)(G0 % RING);        // slot of row G0 - 1
+    auto wrap = [&](unsigned v) { return min(v, v - RINGBYTES); };
+    const unsigned colb = (unsigned)(js + 1) * W3_PIXB + (unsigned)cv8 * 2;
+    if (has_first) *reinterpret_cast<uint4*>(sH + wrap((sG0 + rn0) * RS) + colb) = has_bn ? bn_vec(rfirst) : rfirst;
+    unsigned wsa = wrap((sG0 + 2 + rn0) * RS), wsb = wrap((sG0 + 2 + rn1) * RS);   // tile 0's new rows
+    const unsigned dofs = (unsigned)px * W3_PIXB + (unsigned)cv8 * 2;
+    auto store_x = [&](const uint4& r, unsigned& ws) {
+        *reinterpret_cast<uint4*>(sH + ws + colb) = has_bn ? bn_vec(r) : r;
+        ws = wrap(ws + STEP);
+    };
+    auto store_d = [&](int par) {
+        *reinterpret_cast<uint4*>(sD + (unsigned)par * (W3_TP * W3_PIXB) + dofs) = rda;
+        *reinterpret_cast<uint4*>(sD + (unsigned)par * (W3_TP * W3_PIXB) + dofs + 128 * W3_PIXB) = rdb;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // dbias = column sums of dy, on the matrix pipe at 4 accumulator registers: the dy fragment of the 32x32x16 form (lane l:
+    // channel l & 31, pixels 8 (l >> 5) ..) read as the A operand of v_mfma_f32_16x16x32_bf16 (lane l: row l & 15, k group l >> 4)
+    // puts channel r in k groups 0 / 2 of row r and channel r + 16 in k groups 1 / 3; B selects the even groups into column 0
+    // and the odd ones into column 1, so D[r][0] = sum of channel r, D[r][1] = sum of channel r + 16 (lane l holds rows
+    // 4 (l >> 4) .. + 3 of column l & 15).
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+    const unsigned bsel = (((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
+    const u32x4 bones = {bsel, bsel, bsel, bsel};
+    const bool do_bias = (a.dbias != nullptr) && ct == 0;
+    // this lane's byte offset inside a fragment (mfma_frag.h): pixel 8 * half + (s / 4), channels 16 * (g & 1) + 4 * (s & 3)
+    const unsigned frag_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * W3_PIXB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    // the wave's two k-steps of every tile: pixels 16 wave + 128 h .. + 15 -> tile row th[h], column tj[h]; their running state:
+    // rb[h] = ring offset of tap row 0 (row G + th - 1), ph[h] = image row of the k-step's pixels
+    const int th0 = (wave * 16) >> lgW, th1 = (wave * 16 + 128) >> lgW;
+    const unsigned tj0 = (unsigned)((wave * 16) & (W - 1)) * W3_PIXB, tj1 = (unsigned)((wave * 16 + 128) & (W - 1)) * W3_PIXB;
+    unsigned rb0 = wrap((sG0 + th0) * RS), rb1 = wrap((sG0 + th1) * RS);
+    int ph0 = (G0 + th0) % H, ph1 = (G0 + th1) % H;
+    const unsigned zoff = (unsigned)(sZ - sH);
+
+    store_x(rxa, wsa); store_x(rxb, wsb); store_d(0);
+    loads(G0 + nrows);
+    int G = G0;
+    W3_STAMP();                                                  // 4: first rows + tile 0 stored, next requests issued
+    // iteration i: tile i is multiplied while tile i + 1 is written to the other halves of the buffers (one barrier per tile) and
+    // tile i + 2 is requested.  Past the range's end the (clamped) requests and stores go on: harmless, and branch-free.
+    struct Row { u32x2 a0, a1, c0, c1; };
+    auto mma_row = [&](const bf16x8& af, const Row& o, f32x16& a0, f32x16& a1, f32x16& a2) {
+        const u32x4 b0 = {o.a0[0], o.a0[1], o.a1[0], o.a1[1]};
+        const u32x4 b1 = {__builtin_amdgcn_alignbit(o.c0[0], o.a0[0], 16), __builtin_amdgcn_alignbit(o.c0[1], o.a0[1], 16),
+                          __builtin_amdgcn_alignbit(o.c1[0], o.a1[0], 16), __builtin_amdgcn_alignbit(o.c1[1], o.a1[1], 16)};
+        const u32x4 b2 = {o.c0[0], o.c0[1], o.c1[0], o.c1[1]};
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b2), a2, 0, 0, 0);
+    };
+    // carried across the barrier: the last tap row of the previous tile is multiplied AFTER the barrier, under the LDS latency of
+    // the new tile's first fragment reads (all eight waves request at once there; nothing else would feed the matrix pipe).
+    // Zero operands in front of the first tile.
+    Row rc; rc.a0 = rc.a1 = rc.c0 = rc.c1 = u32x2{0u, 0u};
+    bf16x8 afc = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+    for (int i = 0; i < ntl; ++i) {
+        __syncthreads();                               // tile i complete in LDS; tile i - 1's fragments all read
+        if (i < 6) W3_STAMP();                         // 5 + 2 i: barrier
+        const unsigned char* sDc = sD + (unsigned)(i & 1) * (W3_TP * W3_PIXB) + frag_off;
+        // The three column taps of a tap row read the SAME pixels shifted by one: the s = 0 operand (pixels 0..7 of the lane's
+        // half) and the s = 2 operand (pixels 2..9) are fetched, two transposing reads each, and s = 1 is formed by funnel shifts
+        // of their packed pairs -- 4 reads + 4 v_perm per row instead of 6 reads.  The rows of the two k-steps form a software
+        // pipeline: a row's reads are issued two MFMA groups before its MFMAs, and the staging of tile i + 1 (BN + ReLU on
+        // the vector ALU, LDS stores) and the requests for tile i + 2 sit between the MFMA groups, whose issue slots they fill.
+        auto read_a = [&](unsigned pixb) {
+            union { struct { u32x2 a, b; } h; bf16x8 f; } u;
+            u.h.a = w3_tr(sDc + pixb); u.h.b = w3_tr(sDc + pixb + 4 * W3_PIXB);
+            return u.f;
+        };
+        auto read_row = [&](unsigned rbh, unsigned tjh, int ph, int r) {
+            const unsigned ro = wrap(rbh + (unsigned)r * RS) + tjh;
+            const bool inside = (unsigned)(ph + r - 1) < (unsigned)H;      // uniform: a k-step lies in one image row
+            const unsigned char* base = sH + (inside ? ro : zoff) + frag_off;
+            Row o;
+            o.a0 = w3_tr(base); o.a1 = w3_tr(base + 4 * W3_PIXB); o.c0 = w3_tr(base + 2 * W3_PIXB); o.c1 = w3_tr(base + 6 * W3_PIXB);
+            return o;
+        };
+#define W3_FENCE() __builtin_amdgcn_sched_barrier(0)
+        const bf16x8 af0 = read_a((unsigned)(wave * 16) * W3_PIXB);
+        const Row r00 = read_row(rb0, tj0, ph0, 0);
+        const Row r01 = read_row(rb0, tj0, ph0, 1);
+        W3_FENCE();
+        mma_row(afc, rc, acc[6], acc[7], acc[8]);
+        if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc, __builtin_bit_cast(bf16x8, bones), accb, 0, 0, 0);
+        W3_FENCE();
+        const Row r02 = read_row(rb0, tj0, ph0, 2);
+        W3_FENCE();
+        mma_row(af0, r00, acc[0], acc[1], acc[2]);
+        W3_FENCE();
+        const bf16x8 af1 = read_a((unsigned)(wave * 16 + 128) * W3_PIXB);
+        const Row r10 = read_row(rb1, tj1, ph1, 0);
+        W3_FENCE();
+        store_x(rxa, wsa);
+        mma_row(af0, r01, acc[3], acc[4], acc[5]);
+        W3_FENCE();
+        const Row r11 = read_row(rb1, tj1, ph1, 1);
+        W3_FENCE();
+        store_x(rxb, wsb);
+        mma_row(af0, r02, acc[6], acc[7], acc[8]);
+        if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, __builtin_bit_cast(bf16x8, bones), accb, 0, 0, 0);
+        W3_FENCE();
+        rc = read_row(rb1, tj1, ph1, 2);
+        afc = af1;
+        W3_FENCE();
+        store_d((i + 1) & 1);
+        loads(G + 2 * nrows);
+        mma_row(af1, r10, acc[0], acc[1], acc[2]);
+        W3_FENCE();
+        mma_row(af1, r11, acc[3], acc[4], acc[5]);
+#undef W3_FENCE
+        if (i < 6) W3_STAMP();                         // 6 + 2 i: staging, fragment reads and MFMAs issued
+        G += nrows;
+        rb0 = wrap(rb0 + STEP); rb1 = wrap(rb1 + STEP);
+        ph0 += nrows; if (ph0 >= H) ph0 -= H;          // nrows <= H (w3_grid)
+        ph1 += nrows; if (ph1 >= H) ph1 -= H;
+    }
+    mma_row(afc, rc, acc[6], acc[7], acc[8]);          // the last tile's last tap row
+    if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc, __builtin_bit_cast(bf16x8, bones), accb, 0, 0, 0);
+    W3_STAMP();                                                  // loop done
+
+    // ---- flush: waves 0..7 added in that order, three taps per pass through LDS (16-byte writes: the four rows a lane holds
+    //      of a column), coalesced 4-byte stores to the range's slab ----
+    float* slab = a.partial + (size_t)range * a.partial_stride;
+    f32x4* s_red = reinterpret_cast<f32x4*>(smem);                      // [8 waves][3 taps][4 row groups][64 lanes] x 4 rows
+    auto flush3 = [&](const f32x16& v0, const f32x16& v1, const f32x16& v2, int tap0) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f32x16& v = t == 0 ? v0 : (t == 1 ? v1 : v2);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4)
+                s_red[((wave * 3 + t) * 4 + e4) * 64 + lane] = f32x4{v[4 * e4], v[4 * e4 + 1], v[4 * e4 + 2], v[4 * e4 + 3]};
+        }
+        __syncthreads();
+        // 3 taps x 4 row groups x 64 lanes = 768 sums of 8 x 16 bytes: thread -> (tap, e4, lane) twice
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * W3_BLK;
+            if (id < 768) {
+                const int t = id >> 8, e4 = (id >> 6) & 3, l = id & 63;
+                f32x4 sum = s_red[((0 * 3 + t) * 4 + e4) * 64 + l];
+#pragma unroll
+                for (int w = 1; w < W3_NW; ++w) {
+                    const f32x4 o = s_red[((w * 3 + t) * 4 + e4) * 64 + l];
+                    sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2]; sum[3] += o[3];
+                }
+                const int kk = k0 + 8 * e4 + 4 * (l >> 5), c = c0 + (l & 31);      // accumulator element 4 e4 + j: row 8 e4 + j + 4 (l >> 5)
+                float* dst = slab + ((size_t)kk * 9 + tap0 + t) * C + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(size_t)j * 9 * C] = sum[j];
+            }
+        }
+    };
+    flush3(acc[0], acc[1], acc[2], 0);
+    W3_STAMP();                                                          // first flush pass
+    flush3(acc[3], acc[4], acc[5], 3);
+    flush3(acc[6], acc[7], acc[8], 6);
+    W3_STAMP();                                                          // last flush pass
+    if (do_bias) {                                                       // 8 waves x 32 channels, added in wave order
+        float* s_rb = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if ((lane & 15) < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_rb[wave * W3_CH + 16 * (lane & 15) + 4 * (lane >> 4) + e] = accb[e];
+        }
+        __syncthreads();
+        if (tid < W3_CH) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < W3_NW; ++w) tot += s_rb[w * W3_CH + tid];
+            slab[(size_t)K * 9 * C + k0 + tid] = tot;
+        }
+    }
+#ifdef W3_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        printf("wgrad3 stamps (cycles since entry), %d tiles:", ntl);
+        for (int i = 1; i < w3_ns; ++i) printf(" %lld", w3_stamp[i] - w3_stamp[0]);
+        printf("\n");
+    }
+#endif
+}
+
+}  // namespace
+
+// launch geometry: single source of truth (also tells the caller how many slabs the launch writes)
+static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
+    if (a.dtype != FPD_BF16 || a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.P != a.H || a.Q != a.W) return false;
+    if (a.C % 32 != 0 || a.K % 32 != 0 || a.C > 64 || a.K > 64 || a.C * a.K < 64 * 64) return false;   // C, K <= 32 stays on wgrad_tile<SMALL>
+    if (a.W < 16 || a.W > 64 || (a.W & (a.W - 1)) != 0) return false;
+    const int enabled = getenv("FPD_WGRAD3") ? atoi(getenv("FPD_WGRAD3")) : 1;
+    if (!enabled) return false;
+    g.lgW = 0;
+    while ((1 << g.lgW) < a.W) ++g.lgW;
+    g.nrows = W3_TP / a.W;
+    g.ring = 2 * g.nrows + 2;
+    if ((a.N * a.H) % g.nrows != 0 || g.nrows > a.H) return false;       // whole tiles only, a tile within one image's rows (the student's maps)
+    g.mtiles = a.N * a.H / g.nrows;
+    g.npieces = (a.K / 32) * (a.C / 32);
+    // ranges: >= 2 256-pixel tiles per block (prologue + flush of a block cost several tiles), <= 64 slabs, whole groups of 8 (XCDs)
+    const int max_ranges = getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 64;
+    const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 2;
+    int r = std::min(max_ranges, std::max(1, g.mtiles / std::max(1, min_tiles)));
+    if (r >= 8) r = r / 8 * 8;
+    g.nranges = std::max(1, std::min(r, g.mtiles));
+    g.blocks = cdiv(g.nranges, 8) * 8 * g.npieces;
+    const size_t tiles = 2 * W3_CH * sizeof(float) + (size_t)(g.ring * (a.W + 2) + 2 * W3_TP + W3_ZPIX) * W3_CH * sizeof(bf16_t);
+    g.lds = std::max(tiles, (size_t)W3_RED_BYTES);
+    return true;
+}
+
+// returns 1 when the shape is outside this kernel's domain (or no slabs were given: the single-block flush stays with wgrad_tile)
+int fpd_wgrad3_launch(const fpd_wgrad_t& a, hipStream_t st) {
+    W3Grid g;
+    if (a.partial == nullptr || !w3_grid(a, g)) return 1;
+    static LdsAttr configured;
+    if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&wgrad3_kernel), g.lds)) return rc_;
+    FPD_LAUNCH(wgrad3_kernel, dim3(g.blocks), dim3(W3_BLK), g.lds, st, a, g.nrows, g.lgW, g.npieces, g.nranges, g.mtiles);
+    return 0;
+}
+
+int fpd_wgrad3_partials(const fpd_wgrad_t& a) {
+    W3Grid g;
+    return w3_grid(a, g) ? g.nranges : 0;
+}

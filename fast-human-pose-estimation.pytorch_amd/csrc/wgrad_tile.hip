@@ -448,7 +448,11 @@ __global__ __launch_bounds__(256) void wreduce_kernel(const fpd_wreduce_entry_t*
 }  // namespace
 
 // returns 1 when the shape is outside this kernel's domain
+int fpd_wgrad3_launch(const fpd_wgrad_t& a, hipStream_t st);      // wgrad3.hip: the student's 3x3 64 -> 64 with slabs
+int fpd_wgrad3_partials(const fpd_wgrad_t& a);
+
 int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
+    if (const int rc3 = fpd_wgrad3_launch(a, st); rc3 != 1) return rc3;
     WtGrid g;
     if (!wt_grid(a, g)) return 1;
     if (a.partial != nullptr && a.partial_stride < (int64_t)a.K * a.R * a.S * a.C + a.K)
@@ -462,6 +466,7 @@ int fpd_wgrad_tile_launch(const fpd_wgrad_t& a, hipStream_t st) {
 }
 
 int fpd_wgrad_tile_partials(const fpd_wgrad_t& a) {
+    if (const int n3 = fpd_wgrad3_partials(a)) return n3;
     WtGrid g;
     return wt_grid(a, g) ? g.slabs : 0;
 }

@@ -445,8 +445,10 @@ WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), 
                (2, 64, 48, 32, 32, 3, 1, True), (2, 16, 16, 16, 32, 3, 1, True), (3, 32, 32, 32, 16, 3, 1, False),   # C, K <= 32: wgrad_tile SMALL
                (2, 16, 48, 32, 64, 3, 1, True), (3, 32, 24, 64, 64, 3, 1, True), (2, 64, 48, 32, 32, 1, 0, False),   # HRNet map widths
                (3, 16, 12, 128, 128, 3, 1, True), (2, 32, 24, 64, 32, 1, 0, True), (5, 16, 12, 128, 64, 1, 0, False),
-               (32, 32, 24, 64, 64, 3, 1, True)]
-TILE_ONLY_CASES = WGRAD_CASES[-7:]      # every HRNet width that is a multiple of 4 must be taken by the halo-tile kernel
+               (32, 32, 24, 64, 64, 3, 1, True),
+               (2, 64, 64, 64, 64, 3, 1, True), (32, 16, 16, 64, 64, 3, 1, True), (3, 9, 16, 64, 64, 3, 1, True),   # wgrad3: ring halo, ranges x pieces
+               (8, 64, 64, 64, 64, 3, 1, False), (7, 32, 32, 64, 64, 3, 1, True)]
+TILE_ONLY_CASES = WGRAD_CASES[-12:-5]      # every HRNet width that is a multiple of 4 must be taken by the halo-tile kernel
 
 
 @pytest.mark.parametrize('backend', BACKENDS + ['partials', 'tile_only'])

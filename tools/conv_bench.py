@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--partials', action='store_true', help='weight gradients with slabs (what a training plan uses), reduction not timed')
     ap.add_argument('--no-stats', action='store_true', help='ablation: do not accumulate output statistics')
     ap.add_argument('--graph', action='store_true', help='time a hipGraph of --iters copies (device-side time per launch)')
     args = ap.parse_args()
@@ -84,8 +85,11 @@ def main():
                       epi_bn=None, epi_stats=None, dims=(N, H, W, C, K, Rr, Rr, 1, pad, P, Q))
         plan = R.Plan()
         reps = args.iters if args.graph else 1
-        for _ in range(reps):
-            plan.add(*low.op(op))
+        low.use_partials = args.partials and args.wgrad
+        lowered = [low.op(op) for _ in range(1)] * reps
+        low.finish_partials()
+        for code, st_ in lowered:
+            plan.add(code, st_)
         st = R.current_stream()
         for _ in range(3):
             plan.run(0, 1, st)
@@ -111,7 +115,10 @@ def main():
             l.fpd_event_record(e1, st)
             ms = l.fpd_event_elapsed_ms(e0, e1) / args.iters
         fl = 2.0 * N * P * Q * K * C * Rr * Rr
-        print('%-22s %s %8.1f us  %7.1f TFLOP/s' % (name, 'wgrad' if args.wgrad else 'conv ', ms * 1e3, fl / ms / 1e9), flush=True)
+        extra = ''
+        if args.wgrad and args.partials:
+            extra = '  slabs %d' % sum(r[4] for r in low.partials.values())
+        print('%-22s %s %8.1f us  %7.1f TFLOP/s%s' % (name, 'wgrad' if args.wgrad else 'conv ', ms * 1e3, fl / ms / 1e9, extra), flush=True)
 
 
 if __name__ == '__main__':
