@@ -212,10 +212,10 @@ def conv_classes(step, R, peak_tflops, launches=12, top=6):
 
 def pmc_traffic_of_class(shape_tag, sub):
     """HBM bytes per launch of a convolution class from the committed rocprofv3 --pmc passes of this round, keyed on the shape
-    tag of the library's launch log (profiles/r04_<sub>hbm_traffic.csv, written by tools/profile_summarize.py); (None, why)
+    tag of the library's launch log (profiles/r05_<sub>hbm_traffic.csv, else round 4's, written by tools/profile_summarize.py); (None, why)
     if that table or row is absent."""
     import csv
-    for pfx in ('r04', 'r04a'):
+    for pfx in ('r05', 'r04', 'r04a'):
         path = os.path.join(ROOT, 'profiles', '%s_%shbm_traffic.csv' % (pfx, sub))
         if not os.path.exists(path):
             continue
@@ -257,6 +257,44 @@ def dominant_kernel(step, R, launches=50):
             'per_step': (n_single, n_paired), 'grid_cap': int(os.environ.get('FPD_BNECK_BLOCKS', '128'))}
 
 
+def phase_times(step, R, n=10):
+    """Where a step's time goes (in the driver-visible record, not only in DESIGN.md): every phase of the
+    step's own plans run ALONE -- nothing beside it on the chip -- timed with the host clock around `n` back-to-back runs between
+    device synchronisations; plus the weight-gradient lane's launches (every op of the student's backward that the schedule
+    puts on the lane: weight gradients, slab reductions) re-issued one by one = the lane's serialised kernel time.  Runs after
+    the timed region (the buffers hold stale values: timing only)."""
+    s = step.student
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.time() - t0) / n * 1e3, 3)
+    out = {'teacher_alone_ms': timed(lambda: step.teachers[0].run('fwd')) if step.teachers else None}
+    for ph, key in (('fwd', 'student_fwd_ms'), ('mid', 'student_loss_ms'), ('bwd', 'student_bwd_ms'), ('adam', 'student_adam_ms')):
+        out[key] = timed(lambda ph=ph: s.run(ph))
+
+    def chain():
+        for ph in ('prep', 'fwd', 'mid', 'bwd', 'adam'):
+            s.run(ph)
+    out['student_chain_alone_ms'] = timed(chain)
+    lane_us, lane_n = 0.0, 0
+    for o in s.g.bwd:
+        if getattr(o, 'lane', 0):
+            k = s.op_index.get(id(o))
+            if k is not None and s.plan.op_type(k) != R.OP_NOP:
+                lane_us += time_plan_op(R, s.plan, k, 3)
+                lane_n += 1
+    out['lane_serialised_ms'] = round(lane_us * 1e-3, 3)
+    out['lane_launches'] = lane_n
+    out['note'] = ('each phase of the step\'s own plans alone on the chip, host clock around %d back-to-back runs; '
+                   'lane_serialised_ms = every weight-gradient-lane launch of the backward re-issued 3x on its own (HIP events)' % n)
+    return out
+
+
 def parity_object(build_pair, E, student, teacher, batch, dev, H, W):
     """Accuracy of the build that was just timed (bf16), measured here on the bench batch against the fp32 parity build of
     the same path (the build pinned to the reference within 1e-4 by tests/test_model_gpu.py / test_fullsize_gpu.py): same
@@ -288,14 +326,25 @@ def parity_object(build_pair, E, student, teacher, batch, dev, H, W):
 
     def rl2(u, v):
         return float((u.double() - v.double()).norm() / v.double().norm())
-    res = {'checked_against': 'fp32 parity build of the same path on the bench batch (pinned to the reference <= 1e-4 by the -m gpu tests)',
-           'teacher_map_rel_l2': round(rl2(a['tmap'], b['tmap']), 4), 'last_student_map_rel_l2': round(rl2(a['map'], b['map']), 4),
-           'loss_rel_err': round(abs(a['loss'][2] - b['loss'][2]) / abs(b['loss'][2]), 6),
-           'pose_loss': [round(a['loss'][0], 6), round(b['loss'][0], 6)], 'kd_loss': [round(a['loss'][1], 6), round(b['loss'][1], 6)],
-           'gradient_rel_l2': round(rl2(a['grad'], b['grad']), 4),
-           'note': 'random-init synthetic networks: bf16 WEIGHT rounding alone moves these maps ~30 % and the reference under '
-                   'torch.autocast(bf16) deviates as much (tests/test_bf16_parity_gpu.py holds this build to <= 1.5x the '
-                   'reference-at-bf16 error with an fp64 referee, and to absolute bounds on a trained pair)'}
+    # the map / gradient distances between the two builds on THIS batch are chaos figures of a random-init
+    # network (0.5 / 1.3 relative L2, the reference under autocast(bf16) deviates as much) and are no longer printed; what is
+    # measured live is the agreement of the losses, and the accuracy statement proper is the trained pair at the timed
+    # architecture, whose measured figures the GPU tests write to profiles/ (FPD_WRITE_PARITY_JSON) and this line quotes.
+    res = {'live': {'checked_against': 'fp32 parity build of the same path on the bench batch (pinned to the reference <= 1e-4 by the -m gpu tests)',
+                    'loss_rel_err': round(abs(a['loss'][2] - b['loss'][2]) / abs(b['loss'][2]), 6),
+                    'pose_loss_bf16_fp32': [round(a['loss'][0], 6), round(b['loss'][0], 6)],
+                    'kd_loss_bf16_fp32': [round(a['loss'][1], 6), round(b['loss'][1], 6)]}}
+    for name in ('r05_parity_trained.json',):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            res['trained_pair'] = {k: {'ours_vs_fp64': round(v['ours_vs_fp64'], 5), 'reference_at_bf16_vs_fp64': round(v['reference_at_bf16_vs_fp64'], 5),
+                                       'ceiling': v['ceiling']} for k, v in d.items() if k.startswith('trained')}
+            res['trained_pair_source'] = ('profiles/%s: relative L2 (losses: relative error) against the fp64 oracle, written by tests/test_fullsize_gpu.py::'
+                                          'test_full_architecture_trained_pair_bf16_vs_fp64 (hg8x256 teacher / hg4x128 student trained 240 + 240 Adam steps '
+                                          'on the blob task, B = 8, 256x256) and tests/test_bf16_parity_gpu.py (the committed reference-trained tiny pair) '
+                                          'on an MI355X; "reference_at_bf16" = the reference\'s own arithmetic under torch.autocast(bfloat16)' % name)
+            break
     return res
 
 
@@ -362,6 +411,7 @@ def main():
     ap.add_argument('--no-fp8', action='store_true', help='hrnet_fp8 shapes with bf16 forward convolutions (same-shape A/B of the fp8 path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-fp32-build parity sub-object')
+    ap.add_argument('--no-phase-times', action='store_true', help='skip the per-phase / lane timing after the timed region')
     ap.add_argument('--graphs', action='store_true',
                     help='replay each phase as a hipGraph instead of launching kernel by kernel (same GPU time; with more\n'
                          'than 4 hardware queues ROCm 7.2 graph replay of multi-stream phases is pathologically slow)')
@@ -499,7 +549,7 @@ def main():
         # HBM bytes/launch from separate rocprofv3 --pmc passes (tools/pmc_bneck.sh), only if that file was measured at the
         # launch geometry timed here (grid cap): a file from another geometry is refused, not quoted
         traffic, traffic_note = None, 'no PMC file under profiles/'
-        for name in ('r04_pmc_bneck64.json', 'r04a_pmc_bneck64.json', 'r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
+        for name in ('r05_pmc_bneck64.json', 'r04_pmc_bneck64.json', 'r04a_pmc_bneck64.json', 'r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
@@ -540,6 +590,7 @@ def main():
                     'frac': step_roof['frac'], 'traffic': None, 'note': step_roof['note']}
     if classes is not None:
         roofline['conv_classes'] = classes
+    phases = phase_times(step, R) if (rank == 0 and world == 1 and not args.graphs and not args.no_phase_times) else None
     out = {
         'metric': ('images/sec FPD train step (HRNet-W32 student with fp8 forward convolutions, HRNet-W48 teacher) 384x288' if f8 else
                    'images/sec FPD train step (HRNet-W32 student, HRNet-W48 teacher) 256x192' if hr else
@@ -563,6 +614,8 @@ def main():
                    'loss_last_step': round(loss, 6), 'finite': bool(loss == loss and abs(loss) < 1e6)},
         'roofline': roofline,
     }
+    if phases is not None:
+        out['phase_times'] = phases
     if use_dist:
         out['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
         exp = getattr(allreduce, 'exposed_us', None)

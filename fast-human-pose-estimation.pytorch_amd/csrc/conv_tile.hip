@@ -152,7 +152,10 @@ __device__ __forceinline__ void conv_tile_body(const fpd_conv_t& a, const TileGe
                 const int rem = v - hr * WV;
                 const int j = rem >> LOG_VPR, cv = (rem & (VPR - 1)) * VEC;
                 const int g = g0 - pad + hr;
-                const size_t off = (size_t)(min(max(g, 0), GR - 1) * W + j) * C + c0 + cv;
+                // 32-bit element offset from the (scalar) tensor base: a tensor of this library has < 2^31 elements (checked by the
+                // launcher).  As size_t the NVH per-thread addresses were 64-bit register pairs, which pushed the <bf16, 1, *>
+                // variants two registers over their 128 (an 8-byte spill reloaded in front of a request, r04 code object).
+                const unsigned off = (unsigned)((min(max(g, 0), GR - 1) * W + j) * C + c0 + cv);
                 rh[i] = *reinterpret_cast<const uint4*>(x + off);
                 if constexpr (FOLD) ru[i] = *reinterpret_cast<const uint4*>(fxs + off);
                 hmask |= ((unsigned)g < (unsigned)GR) ? (1u << i) : 0u;
@@ -488,6 +491,7 @@ int launch_tile_tn(const fpd_conv_t& a, hipStream_t st) {
 
 // shapes the halo-tile kernel covers: stride-1 "same" 1x1 / 3x3, rows of at most 128 pixels, C a multiple of 16
 static bool tile_domain(const fpd_conv_t& a) {
+    if ((long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return false;        // 32-bit element offsets in the halo requests
     if (a.stride != 1 || a.R != a.S || (a.R != 1 && a.R != 3) || a.pad != (a.R - 1) / 2) return false;
     if (a.P != a.H || a.Q != a.W || a.W > 128 || a.W < 2) return false;
     if (a.C % 16 != 0 || a.C > FPD_MAXC) return false;

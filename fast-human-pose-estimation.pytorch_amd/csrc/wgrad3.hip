@@ -7,8 +7,8 @@
 // Decomposition: the K x C plane is cut into 32 x 32 PIECES (kt, ct); a block owns one piece for ALL nine taps and walks a
 // CONTIGUOUS range of 128-pixel tiles (whole image rows).  The pieces of one range share an XCD (block b runs on XCD b % 8), so
 // the two readers of every 64-byte half row meet in that XCD's L2 and HBM sees each byte of x and dy once.  A block's
-// accumulator is 9 x 32 x 32 floats = 36 KB, and a gradient is summed from `nranges` slabs (<= 64) instead of 128:
-// 4.7-9.4 MB of slab traffic at 64x64, less below.
+// accumulator is 9 x 32 x 32 floats = 36 KB, and a gradient is summed from `nranges` slabs (32 by default) instead of 128:
+// 4.7 MB of slab traffic at 64x64 instead of 18.9, less below.
 //
 // Per tile a block stages 32 channels of dy (128 pixels x 64 B) and of x: the halo lives in a RING of nrows + 2 image rows in
 // LDS (row g sits in slot (g + 1) % RING), so every x row is fetched ONCE per block (BatchNorm + ReLU applied once per element on
@@ -126,10 +126,14 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, 
     };
     const int G0 = t_begin * nrows;                    // first flat row of the range
     loads(G0);
-    // rows G0 - 1 and G0 come in directly (every later row arrives as a "new row" of some tile): 8 W vectors <= one per thread
+    // rows G0 - 1 and G0 come in directly (every later row arrives as a "new row" of some tile): 8 W vectors = one per thread
+    // up to W = 64, two at W = 128 (vector tid + 512 is the same pixel column of row G0)
     const bool has_first = tid < 8 * W;
-    const int frow = min(max(G0 - 1 + rn0, 0), GR - 1);       // rn0 is 0 / 1 for those threads
+    const int fr0 = W <= 64 ? rn0 : 0;                        // rn0 is 0 / 1 for the threads below 8 W at W <= 64
+    const int frow = min(max(G0 - 1 + fr0, 0), GR - 1);
     const uint4 rfirst = *reinterpret_cast<const uint4*>(x + ((unsigned)frow * xrow + xoff));
+    uint4 rfirst2 = make_uint4(0, 0, 0, 0);
+    if (W > 64) rfirst2 = *reinterpret_cast<const uint4*>(x + ((unsigned)min(G0, GR - 1) * xrow + xoff));
     BnRaw braw;
     if (tid < W3_CH) bn_request(a.bn, c0 + tid, C, braw);
     W3_STAMP();                                                  // 1: prologue requests issued
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, 
     const unsigned sG0 = (unsigned)(G0 % RING);        // slot of row G0 - 1
     auto wrap = [&](unsigned v) { return min(v, v - RINGBYTES); };
     const unsigned colb = (unsigned)(js + 1) * W3_PIXB + (unsigned)cv8 * 2;
-    if (has_first) *reinterpret_cast<uint4*>(sH + wrap((sG0 + rn0) * RS) + colb) = has_bn ? bn_vec(rfirst) : rfirst;
+    if (has_first) *reinterpret_cast<uint4*>(sH + wrap((sG0 + fr0) * RS) + colb) = has_bn ? bn_vec(rfirst) : rfirst;
+    if (W > 64) *reinterpret_cast<uint4*>(sH + wrap((sG0 + 1) * RS) + colb) = has_bn ? bn_vec(rfirst2) : rfirst2;
     unsigned wsa = wrap((sG0 + 2 + rn0) * RS), wsb = wrap((sG0 + 2 + rn1) * RS);   // tile 0's new rows
     const unsigned dofs = (unsigned)px * W3_PIXB + (unsigned)cv8 * 2;
     auto store_x = [&](const uint4& r, unsigned& ws) {
@@ -355,8 +360,9 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, 
 // launch geometry: single source of truth (also tells the caller how many slabs the launch writes)
 static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     if (a.dtype != FPD_BF16 || a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.P != a.H || a.Q != a.W) return false;
-    if (a.C % 32 != 0 || a.K % 32 != 0 || a.C > 64 || a.K > 64 || a.C * a.K < 64 * 64) return false;   // C, K <= 32 stays on wgrad_tile<SMALL>
-    if (a.W < 16 || a.W > 64 || (a.W & (a.W - 1)) != 0) return false;
+    if (!((a.C == 64 && a.K == 64) || (a.C == 32 && a.K == 32))) return false;      // 4 pieces / 1 piece of 32 x 32
+    if (a.W < 16 || a.W > 128 || (a.W & (a.W - 1)) != 0) return false;
+    if ((long long)a.N * a.H * a.W * std::max(a.C, a.K) >= (1ll << 31)) return false;      // 32-bit element offsets in the requests
     const int enabled = getenv("FPD_WGRAD3") ? atoi(getenv("FPD_WGRAD3")) : 1;
     if (!enabled) return false;
     g.lgW = 0;
@@ -367,7 +373,12 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     g.mtiles = a.N * a.H / g.nrows;
     g.npieces = (a.K / 32) * (a.C / 32);
     // ranges: >= 2 256-pixel tiles per block (prologue + flush of a block cost several tiles), <= 64 slabs, whole groups of 8 (XCDs)
-    const int max_ranges = getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 64;
+    // (one piece per range, C = K = 32: a slab is a quarter of the bytes, so four times the ranges fill the chip at the same traffic)
+    // Default 32 ranges = 128 blocks, HALF the chip: alone the 64x64 launch then takes 27.9 us instead of 20.6 (64 ranges), but the
+    // step is faster -- same-box sweep, three interleaved runs each (experiments/r05/g11.sh): 16 / 24 / 32 / 48 / 64 ranges ->
+    // 9.957 / 9.925 / 9.942 / 9.970 / 10.064 ms/step.  The lane is not the critical path; its blocks take compute units from the
+    // student chain, and every range is another slab for the reduction to read.
+    const int max_ranges = (getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 32) * 4 / g.npieces;
     const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 2;
     int r = std::min(max_ranges, std::max(1, g.mtiles / std::max(1, min_tiles)));
     if (r >= 8) r = r / 8 * 8;

@@ -152,7 +152,7 @@ def test_host_side_dispatch_predicates_of_round_3_without_a_device(runtime):
     w.x = w.dy = w.dw = 64
     w.N, w.H, w.W, w.C, w.K, w.R, w.S, w.stride, w.pad, w.P, w.Q = 32, 64, 64, 64, 64, 3, 3, 1, 1, 64, 64
     w.dtype = R.BF16
-    assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) == 64                        # wgrad3 (round 5): one slab per contiguous pixel range, 4 pieces each
+    assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) == 32                        # wgrad3 (round 5): one slab per contiguous pixel range, 4 pieces each
     w.C = w.K = 128
     assert lib.fpd_wgrad_num_partials(ctypes.byref(w)) == 32                        # 3x3 halo-tile kernel: one slab per block, 128 blocks over 4 (k, c) tiles
     w.C = w.K = 64

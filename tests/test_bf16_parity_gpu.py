@@ -89,6 +89,12 @@ TRAINED_GRAD_CEILING = 0.5
 
 def check(label, ours, ref_bf16, floor, ceiling, slack=1.5):
     print('%-34s ours %.3e   reference@bf16 %.3e   (floor %.1e, ceiling %.1e)' % (label, ours, ref_bf16, floor, ceiling))
+    if os.environ.get('FPD_WRITE_PARITY_JSON'):            # the measured figures, for the record bench.py quotes (profiles/)
+        import json
+        path = os.environ['FPD_WRITE_PARITY_JSON']
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d[label] = {'ours_vs_fp64': float(ours), 'reference_at_bf16_vs_fp64': float(ref_bf16), 'floor': floor, 'ceiling': ceiling, 'slack': slack}
+        json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
     assert ours <= max(floor, slack * ref_bf16), (label, 'less accurate than %.1fx the reference at bf16' % slack, ours, ref_bf16)
     assert ours <= ceiling, (label, 'above the absolute ceiling', ours, ceiling)
 

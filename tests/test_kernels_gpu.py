@@ -447,8 +447,9 @@ WGRAD_CASES = [(2, 16, 16, 32, 64, 3, 1, True), (2, 8, 8, 128, 64, 1, 0, True), 
                (3, 16, 12, 128, 128, 3, 1, True), (2, 32, 24, 64, 32, 1, 0, True), (5, 16, 12, 128, 64, 1, 0, False),
                (32, 32, 24, 64, 64, 3, 1, True),
                (2, 64, 64, 64, 64, 3, 1, True), (32, 16, 16, 64, 64, 3, 1, True), (3, 9, 16, 64, 64, 3, 1, True),   # wgrad3: ring halo, ranges x pieces
-               (8, 64, 64, 64, 64, 3, 1, False), (7, 32, 32, 64, 64, 3, 1, True)]
-TILE_ONLY_CASES = WGRAD_CASES[-12:-5]      # every HRNet width that is a multiple of 4 must be taken by the halo-tile kernel
+               (8, 64, 64, 64, 64, 3, 1, False), (7, 32, 32, 64, 64, 3, 1, True),
+               (2, 128, 128, 32, 32, 3, 1, True), (8, 32, 32, 32, 32, 3, 1, True)]      # wgrad3, one piece: the hourglass' layer1 3x3 at 128x128
+TILE_ONLY_CASES = WGRAD_CASES[-14:-7]      # every HRNet width that is a multiple of 4 must be taken by the halo-tile kernel
 
 
 @pytest.mark.parametrize('backend', BACKENDS + ['partials', 'tile_only'])
