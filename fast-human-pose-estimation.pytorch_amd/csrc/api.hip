@@ -728,6 +728,8 @@ int fpd_plan_run_op(fpd_plan* p, int32_t op, fpd_stream_t stream) {
 
 int fpd_plan_capture(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     FPD_REQUIRE(p, "plan_capture: null");
+    // a captured launch is logged once (here) but traced on every replay: the log could no longer be aligned with a trace
+    FPD_REQUIRE(!g_fpd_launch_log, "plan_capture: FPD_LAUNCH_LOG is set -- the launch log keys a kernel trace 1:1 and cannot follow hipGraph replays; unset one of them");
     hipStream_t st = (hipStream_t)stream;
     FPD_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = fpd_plan_run(p, begin, end, stream);

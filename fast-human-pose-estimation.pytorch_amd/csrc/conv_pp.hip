@@ -67,7 +67,10 @@ __device__ __forceinline__ f32x2 bf2_unpack(unsigned w) {
 }
 __device__ __forceinline__ unsigned bf2_pack(f32x2 v) { return f2bf_pk(v[0], v[1]); }
 // max of the two signed 16-bit halves with `lo` in both: lo = 0 is ReLU on a packed bf16 pair (a negative bf16 is a negative
-// int16; rounding is monotonic and keeps the sign, so relu(round(t)) == round(relu(t))), lo = -32768 is the identity
+// int16; rounding is monotonic and keeps the sign, so relu(round(t)) == round(relu(t))), lo = -32768 is the identity.
+// Not the bits of the scalar fmaxf path in two corners: -0.0 becomes +0.0 (equal as an MFMA operand and in
+// every sum), and a NaN survives with its sign bit clear / becomes 0 with it set, where fmaxf(NaN, 0) = 0 -- a NaN activation
+// means the step has diverged either way; the cross-kernel bit tests use finite inputs.
 __device__ __forceinline__ unsigned bf2_floor(unsigned w, short lo) {
     s16x2 a = *reinterpret_cast<const s16x2*>(&w);
     const s16x2 b = {lo, lo};

@@ -355,6 +355,320 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, 
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wgrad3s: the same decomposition with SPECIALISED waves.  The uniform kernel above runs every wave through staging AND multiplying;
+// its tile loop is bound by instruction issue (two waves per SIMD share one issue port: 225 instructions per wave and tile against
+// 20 MFMAs, r05 PMC: the matrix pipe 25 % busy, 29 % of the wave cycles issue stalls) and its final cross-wave sum moves eight
+// 36 KB accumulator sets through the LDS.  Here waves 0..3 -- one per SIMD -- ONLY read fragments and multiply (four k-steps of a
+// tile each: 56 transposing reads + 48 funnel shifts + 38 MFMAs, about 190 instructions for 1 216 cycles of matrix pipe), and
+// waves 4..7 ONLY stage: they request tile i + 2, apply BN + ReLU to tile i + 1 and store it, then park at the tile barrier without
+// taking issue slots.  Four accumulator sets instead of eight go through the LDS at the end.
+template <int DUMMY>
+__global__ __launch_bounds__(W3_BLK, 2) void wgrad3s_kernel(const fpd_wgrad_t a, const int nrows, const int lgW, const int npieces,
+                                                            const int nranges, const int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mma_wave = wave < 4;
+    const int H = a.H, W = a.W, C = a.C, K = a.K;
+    const int GR = a.N * H;
+    const int WP = W + 2, RING = 2 * nrows + 2;
+    const unsigned RS = (unsigned)WP * W3_PIXB;
+    const unsigned RINGBYTES = (unsigned)RING * RS, STEP = (unsigned)nrows * RS;
+    const int b = blockIdx.x, q = b >> 3;
+    const int piece = q % npieces, range = (q / npieces) * 8 + (b & 7);
+    if (range >= nranges) return;
+    const int cpieces = C / W3_CH;
+    const int kt = piece / cpieces, ct = piece - kt * cpieces;
+    const int k0 = kt * W3_CH, c0 = ct * W3_CH;
+    const int t_begin = (int)(((long long)range * mtiles) / nranges), t_end = (int)(((long long)(range + 1) * mtiles) / nranges);
+    const int ntl = t_end - t_begin;
+#ifdef W3_TIMING
+    if (threadIdx.x == 0) w3_ns = 0;
+#endif
+    W3_STAMP();                                                  // 0: entry
+    float* s_scale = reinterpret_cast<float*>(smem);
+    float* s_shift = s_scale + W3_CH;
+    unsigned char* sH = smem + 2 * W3_CH * sizeof(float);
+    unsigned char* sD = sH + RINGBYTES;
+    unsigned char* sZ = sD + 2 * W3_TP * W3_PIXB;
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+    const short floor_ = a.bn.relu ? (short)0 : (short)-32768;
+    const bool has_bn = a.bn.mode != FPD_BN_NONE;
+    auto wrap = [&](unsigned v) { return min(v, v - RINGBYTES); };
+    const int G0 = t_begin * nrows;
+    const unsigned sG0 = (unsigned)(G0 % RING);        // slot of row G0 - 1 (slot(row) = (row + 1) % RING)
+    const bool do_bias = (a.dbias != nullptr) && ct == 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+
+    if (!mma_wave) {
+        // =============================== staging waves: 256 threads move a whole tile ===============================
+        // thread t: channels cv8 .. + 7 of pixels p0 + 64 v, v = 0..3 (p0 = t / 4), of the tile's new x rows and of its dy rows
+        const int t = tid - 256;
+        const int cv8 = (t & 3) * 8, p0 = t >> 2;
+        const unsigned xrow = (unsigned)(W * C), drow = (unsigned)(W * K);
+        int rn[4];
+        unsigned xoff[4], doff[4], colb[4], ws[4], dofs[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pxv = p0 + 64 * v, js = pxv & (W - 1);
+            rn[v] = pxv >> lgW;
+            xoff[v] = (unsigned)(js * C + c0 + cv8);
+            doff[v] = (unsigned)rn[v] * drow + (unsigned)(js * K + k0 + cv8);
+            colb[v] = (unsigned)(js + 1) * W3_PIXB + (unsigned)cv8 * 2;
+            ws[v] = wrap((sG0 + 2 + rn[v]) * RS);                            // tile 0's new rows
+            dofs[v] = (unsigned)pxv * W3_PIXB + (unsigned)cv8 * 2;
+        }
+        // (named registers, not arrays: arrays written in one lambda and read in another stayed in scratch memory, and a scratch
+        //  round trip of a prefetched vector waits for the request it was supposed to hide)
+        uint4 rx0, rx1, rx2, rx3, rd0, rd1, rd2, rd3;
+#define W3_LOAD1(v, RX, RD) { const unsigned r_ = (unsigned)min(Gc_ + 1 + rn[v], GR - 1);                 \
+                              RX = *reinterpret_cast<const uint4*>(x + (r_ * xrow + xoff[v]));              \
+                              RD = *reinterpret_cast<const uint4*>(dyt_ + doff[v]); }
+#define W3_LOADS(Gt) { const int Gc_ = min((Gt), GR - nrows); const bf16_t* dyt_ = dy + (size_t)Gc_ * drow;   \
+                       W3_LOAD1(0, rx0, rd0) W3_LOAD1(1, rx1, rd1) W3_LOAD1(2, rx2, rd2) W3_LOAD1(3, rx3, rd3) }
+        W3_LOADS(G0)
+        // rows G0 - 1 and G0: 8 W vectors over 256 threads (1 .. 4 each): vector u = t + 256 j is channel chunk u & 3 of pixel u / 4
+        // of the two-row strip
+        uint4 rf0, rf1, rf2, rf3;
+#define W3_FIRST_LD(j, RF) { RF = make_uint4(0, 0, 0, 0); const int u = t + 256 * j, pu = u >> 2, rr = pu >> lgW, ju = pu & (W - 1);      \
+                             const int frow = min(max(G0 - 1 + rr, 0), GR - 1);                                                             \
+                             if (u < 8 * W) RF = *reinterpret_cast<const uint4*>(x + ((unsigned)frow * xrow + (unsigned)(ju * C + c0 + cv8))); }
+        W3_FIRST_LD(0, rf0) W3_FIRST_LD(1, rf1) W3_FIRST_LD(2, rf2) W3_FIRST_LD(3, rf3)
+#undef W3_FIRST_LD
+        W3_STAMP();
+        __syncthreads();                               // scale / shift table (written by wave 0), border zeros
+        f32x2 psc[4], psh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            psc[e] = *reinterpret_cast<const f32x2*>(s_scale + cv8 + 2 * e);
+            psh[e] = *reinterpret_cast<const f32x2*>(s_shift + cv8 + 2 * e);
+        }
+        auto bn_vec = [&](const uint4 r) {
+            return make_uint4(w3_bn2(r.x, psc[0], psh[0], floor_), w3_bn2(r.y, psc[1], psh[1], floor_),
+                              w3_bn2(r.z, psc[2], psh[2], floor_), w3_bn2(r.w, psc[3], psh[3], floor_));
+        };
+#define W3_FIRST_ST(j, RF) { const int u = t + 256 * j, pu = u >> 2, rr = pu >> lgW, ju = pu & (W - 1);                                   \
+                             if (u < 8 * W) *reinterpret_cast<uint4*>(sH + wrap((sG0 + rr) * RS) + (unsigned)(ju + 1) * W3_PIXB + (unsigned)cv8 * 2) = has_bn ? bn_vec(RF) : RF; }
+        W3_FIRST_ST(0, rf0) W3_FIRST_ST(1, rf1) W3_FIRST_ST(2, rf2) W3_FIRST_ST(3, rf3)
+#undef W3_FIRST_ST
+#define W3_STORE1(v, RX, RD, par) { *reinterpret_cast<uint4*>(sH + ws[v] + colb[v]) = has_bn ? bn_vec(RX) : RX;      \
+                                    ws[v] = wrap(ws[v] + STEP);                                                       \
+                                    *reinterpret_cast<uint4*>(sD + (unsigned)(par) * (W3_TP * W3_PIXB) + dofs[v]) = RD; }
+#define W3_STORES(par) { W3_STORE1(0, rx0, rd0, par) W3_STORE1(1, rx1, rd1, par) W3_STORE1(2, rx2, rd2, par) W3_STORE1(3, rx3, rd3, par) }
+        W3_STORES(0)
+        W3_LOADS(G0 + nrows)
+        int G = G0;
+        for (int i = 0; i < ntl; ++i) {
+            __syncthreads();                           // tile i complete; the multiplying waves are done with tile i - 1
+            W3_STORES((i + 1) & 1)
+            W3_LOADS(G + 2 * nrows)
+            G += nrows;
+        }
+#undef W3_LOAD1
+#undef W3_LOADS
+#undef W3_STORE1
+#undef W3_STORES
+    } else {
+        // =============================== multiplying waves: one per SIMD ===============================
+        BnRaw braw;
+        if (tid < W3_CH) bn_request(a.bn, c0 + tid, C, braw);
+        for (int v = tid; v < (2 * RING + W3_ZPIX) * 4; v += 256) {           // border columns of the ring rows + the zero pixels
+            const int pz = v >> 2;
+            unsigned char* dst = pz < 2 * RING ? sH + (unsigned)(pz >> 1) * RS + (unsigned)(pz & 1) * (unsigned)(W + 1) * W3_PIXB
+                                                : sZ + (unsigned)(pz - 2 * RING) * W3_PIXB;
+            *reinterpret_cast<uint4*>(dst + (v & 3) * 16) = make_uint4(0, 0, 0, 0);
+        }
+        if (tid < W3_CH) {
+            float sc = 1.f, sh = 0.f, mu, is;
+            if (has_bn) bn_resolve(braw, (double)a.N * H * W, sc, sh, mu, is);
+            s_scale[tid] = sc; s_shift[tid] = sh;
+        }
+        W3_STAMP();                                                  // 1: tables written
+        __syncthreads();
+        const unsigned bsel = (((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
+        const u32x4 bones = {bsel, bsel, bsel, bsel};
+        const unsigned frag_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * W3_PIXB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+        const unsigned zoff = (unsigned)(sZ - sH);
+        // this wave's four k-steps of a tile: pixels 16 (wave + 4 h) .. + 15, h = 0..3
+        unsigned rb[4], tj[4], pxb[4];
+        int ph[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int pix0 = (wave + 4 * h) * 16;
+            const int th = pix0 >> lgW;
+            tj[h] = (unsigned)(pix0 & (W - 1)) * W3_PIXB;
+            pxb[h] = (unsigned)pix0 * W3_PIXB;
+            rb[h] = wrap((sG0 + th) * RS);
+            ph[h] = (G0 + th) % H;
+        }
+        struct Row { u32x2 a0, a1, c0, c1; };
+        auto mma_row = [&](const bf16x8& af, const Row& o, f32x16& a0, f32x16& a1, f32x16& a2) {
+            const u32x4 b0 = {o.a0[0], o.a0[1], o.a1[0], o.a1[1]};
+            const u32x4 b1 = {__builtin_amdgcn_alignbit(o.c0[0], o.a0[0], 16), __builtin_amdgcn_alignbit(o.c0[1], o.a0[1], 16),
+                              __builtin_amdgcn_alignbit(o.c1[0], o.a1[0], 16), __builtin_amdgcn_alignbit(o.c1[1], o.a1[1], 16)};
+            const u32x4 b2 = {o.c0[0], o.c0[1], o.c1[0], o.c1[1]};
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1), a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b2), a2, 0, 0, 0);
+        };
+        // group g = 3 h + r (k-step h, tap row r) of a tile; the reads of group g + 2 are issued in front of the MFMAs of group g,
+        // and the last group of a tile is multiplied behind the NEXT tile's barrier, under its first reads (zeros before tile 0)
+        Row rw0, rw1, rw2;                               // group g lives in rw[g % 3]
+        rw2.a0 = rw2.a1 = rw2.c0 = rw2.c1 = u32x2{0u, 0u};
+        bf16x8 afA = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}), afB = afA;      // dy fragment of k-step h lives in af[h % 2]
+        afB = afA;                                        // carried: k-step 3 of the previous tile = afB
+        for (int i = 0; i < ntl; ++i) {
+            __syncthreads();
+            if (i < 6) W3_STAMP();
+            const unsigned char* sDc = sD + (unsigned)(i & 1) * (W3_TP * W3_PIXB) + frag_off;
+            auto read_a = [&](int h) {
+                union { struct { u32x2 a, b; } hh; bf16x8 f; } u;
+                u.hh.a = w3_tr(sDc + pxb[h]); u.hh.b = w3_tr(sDc + pxb[h] + 4 * W3_PIXB);
+                return u.f;
+            };
+            auto read_row = [&](int h, int r) {
+                const unsigned ro = wrap(rb[h] + (unsigned)r * RS) + tj[h];
+                const bool inside = (unsigned)(ph[h] + r - 1) < (unsigned)H;
+                const unsigned char* base = sH + (inside ? ro : zoff) + frag_off;
+                Row o;
+                o.a0 = w3_tr(base); o.a1 = w3_tr(base + 4 * W3_PIXB); o.c0 = w3_tr(base + 2 * W3_PIXB); o.c1 = w3_tr(base + 6 * W3_PIXB);
+                return o;
+            };
+#define W3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define W3_BIAS(af) if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bones), accb, 0, 0, 0)
+            // carried group 11 of the previous tile sits in rw2 / afB (k-step 3)
+            const bf16x8 afc = afB;
+            afA = read_a(0);
+            rw0 = read_row(0, 0);                                  // g 0
+            rw1 = read_row(0, 1);                                  // g 1
+            W3_FENCE();
+            mma_row(afc, rw2, acc[6], acc[7], acc[8]); W3_BIAS(afc);          // carried g 11
+            W3_FENCE();
+            rw2 = read_row(0, 2);                                  // g 2
+            W3_FENCE();
+            mma_row(afA, rw0, acc[0], acc[1], acc[2]);            // g 0
+            W3_FENCE();
+            afB = read_a(1); rw0 = read_row(1, 0);                 // g 3
+            W3_FENCE();
+            mma_row(afA, rw1, acc[3], acc[4], acc[5]);            // g 1
+            W3_FENCE();
+            rw1 = read_row(1, 1);                                  // g 4
+            W3_FENCE();
+            mma_row(afA, rw2, acc[6], acc[7], acc[8]); W3_BIAS(afA);          // g 2
+            W3_FENCE();
+            rw2 = read_row(1, 2);                                  // g 5
+            W3_FENCE();
+            mma_row(afB, rw0, acc[0], acc[1], acc[2]);            // g 3
+            W3_FENCE();
+            afA = read_a(2); rw0 = read_row(2, 0);                 // g 6
+            W3_FENCE();
+            mma_row(afB, rw1, acc[3], acc[4], acc[5]);            // g 4
+            W3_FENCE();
+            rw1 = read_row(2, 1);                                  // g 7
+            W3_FENCE();
+            mma_row(afB, rw2, acc[6], acc[7], acc[8]); W3_BIAS(afB);          // g 5
+            W3_FENCE();
+            rw2 = read_row(2, 2);                                  // g 8
+            W3_FENCE();
+            mma_row(afA, rw0, acc[0], acc[1], acc[2]);            // g 6
+            W3_FENCE();
+            afB = read_a(3); rw0 = read_row(3, 0);                 // g 9
+            W3_FENCE();
+            mma_row(afA, rw1, acc[3], acc[4], acc[5]);            // g 7
+            W3_FENCE();
+            rw1 = read_row(3, 1);                                  // g 10
+            W3_FENCE();
+            mma_row(afA, rw2, acc[6], acc[7], acc[8]); W3_BIAS(afA);          // g 8
+            W3_FENCE();
+            rw2 = read_row(3, 2);                                  // g 11: carried
+            W3_FENCE();
+            mma_row(afB, rw0, acc[0], acc[1], acc[2]);            // g 9
+            W3_FENCE();
+            mma_row(afB, rw1, acc[3], acc[4], acc[5]);            // g 10
+            if (i < 6) W3_STAMP();
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                rb[h] = wrap(rb[h] + STEP);
+                ph[h] += nrows; if (ph[h] >= H) ph[h] -= H;
+            }
+        }
+        mma_row(afB, rw2, acc[6], acc[7], acc[8]); W3_BIAS(afB);              // the last tile's last group
+#undef W3_FENCE
+#undef W3_BIAS
+    }
+    W3_STAMP();                                                  // loop done
+
+    // ---- flush: the four multiplying waves' accumulators added in wave order, three taps per pass through LDS ----
+    float* slab = a.partial + (size_t)range * a.partial_stride;
+    f32x4* s_red = reinterpret_cast<f32x4*>(smem);                      // [4 waves][3 taps][4 row groups][64 lanes] x 4 rows
+    auto flush3 = [&](const f32x16& v0, const f32x16& v1, const f32x16& v2, int tap0) {
+        __syncthreads();
+        if (mma_wave) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f32x16& v = t == 0 ? v0 : (t == 1 ? v1 : v2);
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4)
+                    s_red[((wave * 3 + t) * 4 + e4) * 64 + lane] = f32x4{v[4 * e4], v[4 * e4 + 1], v[4 * e4 + 2], v[4 * e4 + 3]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * W3_BLK;
+            if (id < 768) {
+                const int t = id >> 8, e4 = (id >> 6) & 3, l = id & 63;
+                f32x4 sum = s_red[((0 * 3 + t) * 4 + e4) * 64 + l];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 o = s_red[((w * 3 + t) * 4 + e4) * 64 + l];
+                    sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2]; sum[3] += o[3];
+                }
+                const int kk = k0 + 8 * e4 + 4 * (l >> 5), c = c0 + (l & 31);
+                float* dst = slab + ((size_t)kk * 9 + tap0 + t) * C + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(size_t)j * 9 * C] = sum[j];
+            }
+        }
+    };
+    flush3(acc[0], acc[1], acc[2], 0);
+    W3_STAMP();
+    flush3(acc[3], acc[4], acc[5], 3);
+    flush3(acc[6], acc[7], acc[8], 6);
+    W3_STAMP();
+    if (do_bias) {
+        float* s_rb = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if (mma_wave && (lane & 15) < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_rb[wave * W3_CH + 16 * (lane & 15) + 4 * (lane >> 4) + e] = accb[e];
+        }
+        __syncthreads();
+        if (tid < W3_CH) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += s_rb[w * W3_CH + tid];
+            slab[(size_t)K * 9 * C + k0 + tid] = tot;
+        }
+    }
+#ifdef W3_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        printf("wgrad3s stamps (cycles since entry), %d tiles:", ntl);
+        for (int i = 1; i < w3_ns; ++i) printf(" %lld", w3_stamp[i] - w3_stamp[0]);
+        printf("\n");
+    }
+#endif
+}
+
 }  // namespace
 
 // launch geometry: single source of truth (also tells the caller how many slabs the launch writes)
@@ -372,14 +686,14 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     if ((a.N * a.H) % g.nrows != 0 || g.nrows > a.H) return false;       // whole tiles only, a tile within one image's rows (the student's maps)
     g.mtiles = a.N * a.H / g.nrows;
     g.npieces = (a.K / 32) * (a.C / 32);
-    // ranges: >= 2 256-pixel tiles per block (prologue + flush of a block cost several tiles), <= 64 slabs, whole groups of 8 (XCDs)
+    // ranges: >= 4 256-pixel tiles per block (prologue + flush of a block cost several tiles; a range is a 144 KB slab), <= 64 slabs, whole groups of 8 (XCDs)
     // (one piece per range, C = K = 32: a slab is a quarter of the bytes, so four times the ranges fill the chip at the same traffic)
     // Default 32 ranges = 128 blocks, HALF the chip: alone the 64x64 launch then takes 27.9 us instead of 20.6 (64 ranges), but the
     // step is faster -- same-box sweep, three interleaved runs each (experiments/r05/g11.sh): 16 / 24 / 32 / 48 / 64 ranges ->
     // 9.957 / 9.925 / 9.942 / 9.970 / 10.064 ms/step.  The lane is not the critical path; its blocks take compute units from the
     // student chain, and every range is another slab for the reduction to read.
     const int max_ranges = (getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 32) * 4 / g.npieces;
-    const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 2;
+    const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 4;
     int r = std::min(max_ranges, std::max(1, g.mtiles / std::max(1, min_tiles)));
     if (r >= 8) r = r / 8 * 8;
     g.nranges = std::max(1, std::min(r, g.mtiles));
@@ -393,6 +707,13 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
 int fpd_wgrad3_launch(const fpd_wgrad_t& a, hipStream_t st) {
     W3Grid g;
     if (a.partial == nullptr || !w3_grid(a, g)) return 1;
+    const int spec = getenv("FPD_WGRAD3_SPEC") ? atoi(getenv("FPD_WGRAD3_SPEC")) : 1;      // 1: specialised waves (wgrad3s), 0: uniform
+    if (spec) {
+        static LdsAttr configured_s;
+        if (int rc_ = configured_s.ensure(reinterpret_cast<const void*>(&wgrad3s_kernel<0>), g.lds)) return rc_;
+        FPD_LAUNCH(wgrad3s_kernel<0>, dim3(g.blocks), dim3(W3_BLK), g.lds, st, a, g.nrows, g.lgW, g.npieces, g.nranges, g.mtiles);
+        return 0;
+    }
     static LdsAttr configured;
     if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&wgrad3_kernel), g.lds)) return rc_;
     FPD_LAUNCH(wgrad3_kernel, dim3(g.blocks), dim3(W3_BLK), g.lds, st, a, g.nrows, g.lgW, g.npieces, g.nranges, g.mtiles);

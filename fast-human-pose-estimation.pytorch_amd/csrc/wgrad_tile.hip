@@ -387,6 +387,9 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
     if (const char* e = getenv(a.R == 1 ? "FPD_WGRAD_BLOCKS_1" : "FPD_WGRAD_BLOCKS_3")) target = atoi(e);   // per filter size
     g.gx = std::max(1, std::min(g.mtiles, cdiv(target, g.gy)));
+    // 1x1 on the small maps: a block per 128-pixel tile meant 128 slabs of 32 KB for an 8 192-pixel problem (34 MB per gradient
+    // class and step, r05 slab inventory) at the launch-latency floor either way: at least four tiles per block
+    if (a.R == 1 && g.mtiles <= 256) g.gx = std::max(1, std::min(g.gx, cdiv(g.mtiles, 4)));
     const int nt = a.R * a.R * (cw / 32) * (cw / 32);
     g.slabs = g.gx * (nt <= 4 ? 2 : 1);          // KSPLIT kernels write one slab per wave group
     return true;

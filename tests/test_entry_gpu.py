@@ -274,7 +274,9 @@ def test_launch_log_keys_every_kernel_launch_on_its_plan_op_and_shape(tmp_path):
     assert {'conv', 'ew', 'wgrad', 'loss', 'adam', 'stem_fwd', 'wprep'} <= kinds, kinds
     convs = [f for f in lines if f[4].startswith('conv ')]
     assert all(' N=2 ' in f[4] and ' C=' in f[4] and (' fwd' in f[4] or ' dgrad' in f[4]) for f in convs), convs[:3]
-    assert any('+wgrad' in f[4] or '+fold' in f[4] for f in convs) or True      # (fusions depend on the launch sizes: tiny maps may have none)
+    # the lowering-time fusions leave their tag: every Bottleneck of the tiny student has BN-backward applies that the FOLD variants of
+    # the halo-tile kernel evaluate (size-independent); '+wgrad' needs a persistent-kernel launch (>= 256 tiles), which tiny maps lack
+    assert any('+fold' in f[4] for f in convs), sorted({f[4].split(' R=')[0] for f in convs})[:5]
     assert all(f[1].isdigit() and f[2].isdigit() and f[3].lstrip('-').isdigit() for f in lines)
     # plan ops and logged launches agree: memsets are not kernels of the library, adam is two launches (update + tick)
     n_ops = int(out.stdout.split('LAUNCHES')[1].split()[0])

@@ -3,6 +3,8 @@ row of profiles/*_per_shape.csv / *_hbm_traffic.csv on the tensor shape (tools/t
 and tools/trace_ab.py)."""
 import os
 import random
+
+import pytest
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
@@ -90,3 +92,23 @@ def test_truncated_trace_keys_the_common_prefix_only():
 def test_log_lines_without_a_shape_tag_or_too_short_are_tolerated():
     log = trace_align.parse_log(['adam_kernel\t1\t256\t7\n', 'garbage\n', '(ew_kernel<T, OP>)\t4\t256\t8\tew add N=1 H=2 W=2 C=16\n'])
     assert log == [('adam_kernel', 1, 256, '7', ''), ('ew_kernel', 4, 256, '8', 'ew add N=1 H=2 W=2 C=16')]
+
+
+
+def test_strict_alignment_refuses_count_drift_and_geometry_mismatch():
+    """a count difference between log and trace shifts every later pairing without a name mismatch as long as the
+    kernel repeats (graph replays, truncated traces); the tables under profiles/ are built with strict=True, which raises.  Where
+    the trace carries Grid_Size / Workgroup_Size the pairing is also held to the logged launch geometry."""
+    log_lines, rows, want = _synthetic(nsteps=2, seed=7)
+    log = trace_align.parse_log(log_lines)
+    tags, bad, _, _ = trace_align.align(log, rows, strict=True)
+    assert bad == 0 and tags == want
+    with pytest.raises(ValueError):
+        trace_align.align(log[:-1], rows, strict=True)                  # one launch missing from the log: drift
+    geo = [dict(r, Grid_Size=str(256 * 512), Workgroup_Size='512') for r in rows]
+    assert trace_align.align(log, geo, strict=True)[1] == 0
+    wrong = [dict(r, Grid_Size=str(128 * 512), Workgroup_Size='512') if r['Dispatch_Id'] == sorted(want, key=int)[0] else r for r in geo]
+    tags2, bad2, _, _ = trace_align.align(log, wrong)
+    assert bad2 == 1 and len(tags2) == len(want) - 1
+    with pytest.raises(ValueError):
+        trace_align.align(log, wrong, strict=True)

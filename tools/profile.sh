@@ -13,7 +13,7 @@ PFX="${1:-r04}"
 OUT="$ROOT/gpurun_out/${PFX}prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-parity"
+B="python $ROOT/bench.py --no-cpu-baseline --no-parity --no-phase-times"
 pass() {   # directory, rocprofv3 options..., --, command
   local d="$OUT/$1"; shift
   mkdir -p "$d"

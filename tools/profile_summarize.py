@@ -56,9 +56,7 @@ def shapes_by_dispatch(sub, rows):
     if not log:
         print('%s: no launch log -- rows are keyed on (kernel, grid) only' % sub)
         return {}
-    tags, bad, n_trace, n_log = trace_align.align(log, rows)
-    if n_trace != n_log:
-        print('%s: %d trace rows of library kernels vs %d logged launches -- aligning the common prefix' % (sub, n_trace, n_log))
+    tags, bad, n_trace, n_log = trace_align.align(log, rows, strict=os.environ.get('FPD_ALIGN_LENIENT') != '1')   # drift = wrong keys: an error
     print('%s: %d launches keyed on their shape, %d name mismatches' % (sub, len(tags), bad))
     return tags
 

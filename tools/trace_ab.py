@@ -22,7 +22,7 @@ def run(tag, lib):
     else:
         env.pop('FPD_AMD_LIB', None)
     subprocess.run(['rocprofv3', '--kernel-trace', '-f', 'csv', '-d', d, '-o', 'b', '--', sys.executable, os.path.join(root, 'bench.py'),
-                    '--no-cpu-baseline', '--no-parity', '--steps', '12', '--warmup', '4'], cwd='/tmp', env=env,
+                    '--no-cpu-baseline', '--no-parity', '--no-phase-times', '--steps', '12', '--warmup', '4'], cwd='/tmp', env=env,
                    stdout=open(d + '.log', 'w'), stderr=subprocess.STDOUT)
     rows = [r for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True) for r in csv.DictReader(open(f))]
     log = trace_align.parse_log(open(os.path.join(d, 'launch.log')))
