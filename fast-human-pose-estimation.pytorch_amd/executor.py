@@ -86,7 +86,7 @@ def _abuf(a):
 # no-ops, which shows what that class costs inside the pipelined step (experiments/r03/whatif.sh).  Student graph:
 # nowgrad / nowgrad_small / nowgrad_big (weight gradients, by map height <= 16 / >= 64), noapply (BN-backward applies),
 # nobigconv (convolutions on >= 64x64 maps), nobig / nomid / nosmall (every op on >= 64 / 32 / <= 16 high maps, weight
-# gradients excepted), noew.  Teacher graph: t_all, t_big, t_mid, t_small.
+# gradients excepted), noew.  Teacher graph: t_all, t_big, t_mid, t_small; t_bneck_big / t_head / t_plain_big (the >= 64-high ops by kind).
 _WHATIF = frozenset(t for t in os.environ.get('FPD_WHATIF', '').split(',') if t)
 if _WHATIF:
     import sys
@@ -106,6 +106,11 @@ def _whatif_drop(op, train):
     if not train:
         if k not in ('conv', 'bneck', 'head', 'ew', 'stem_fwd'):
             return False
+        # round 5: the teacher's >= 64-high ops by kind -- fused Bottlenecks (persistent, capped grid), fused heads, and the rest
+        # (stem, layer1 / layer2 convolutions, max-pool: plain full-grid launches)
+        if h >= 64 and (('t_bneck_big' in _WHATIF and k == 'bneck') or ('t_head' in _WHATIF and k == 'head') or
+                        ('t_plain_big' in _WHATIF and k in ('conv', 'ew', 'stem_fwd'))):
+            return True
         return ('t_all' in _WHATIF or ('t_big' in _WHATIF and h >= 64) or ('t_mid' in _WHATIF and h == 32) or
                 ('t_small' in _WHATIF and h <= 16))
     if k in ('wgrad', 'stem_wgrad', 'wreduce'):
