@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# round 5 call 17: stem_s2d v2 (batched prologue requests, epilogue straight from the accumulators, one statistics flush per block)
+cd "$(dirname "$0")/../.." || exit 1
+O=gpurun_out/r05g17; mkdir -p $O
+timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --maxfail=10 --tb=short -p no:cacheprovider -k "stem" > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/pytest.txt
+grep -v "^  File\|^Thread" $O/pytest.txt | tail -6 | cut -c1-300
+echo "== im2col"; FPD_STEM_S2D=0 timeout 200 python tools/stem_bench.py 2>&1 | tail -2
+echo "== s2d"; timeout 200 python tools/stem_bench.py 2>&1 | tail -2
+echo "== s2d 256 / 1024 blocks"; FPD_STEM_BLOCKS=256 timeout 200 python tools/stem_bench.py 2>&1 | tail -2; FPD_STEM_BLOCKS=1024 timeout 200 python tools/stem_bench.py 2>&1 | tail -2
+run() { timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-parity --no-phase-times 2> $O/err_$1.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'])"; }
+for i in 1 2 3; do
+  FPD_STEM_S2D=0 run old_$i
+  run s2d_$i
+done
+echo "== stamps"; FPD_AMD_LIB=$PWD/build_ab/s2t/libfpd_amd.so python tools/stem_bench.py --iters 2 2>&1 | grep stamps | awk "NR==1 || NR==6" | tee $O/stamps.txt
+timeout 600 python -m pytest tests/test_model_gpu.py tests/test_exact_gpu.py -m gpu -q --maxfail=5 --tb=short -p no:cacheprovider > $O/pytest2.txt 2>&1; echo "pytest2 rc=$?" >> $O/pytest2.txt; tail -3 $O/pytest2.txt | cut -c1-200

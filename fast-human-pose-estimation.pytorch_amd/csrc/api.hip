@@ -49,6 +49,7 @@ int fpd_conv_naive_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
@@ -328,7 +329,8 @@ int fpd_stem_forward(const fpd_stem_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a && a->x && a->w && a->bias && a->y, "stem: null pointer");
     FPD_REQUIRE(a->P == (a->H + 6 - 7) / 2 + 1 && a->Q == (a->W + 6 - 7) / 2 + 1, "stem: bad output size");
     int rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_forward_mfma_launch(*a, (hipStream_t)stream);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_forward_s2d_launch(*a, (hipStream_t)stream);      // space-to-depth 4x4 form (round 5)
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_forward_mfma_launch(*a, (hipStream_t)stream);
     if (rc == 1) rc = fpd_stem_forward_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }
