@@ -50,6 +50,8 @@ int fpd_wgrad_naive_launch(const fpd_wgrad_t& a, hipStream_t st);
 int fpd_stem_forward_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_forward_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_wgrad_s2d_launch(const fpd_stem_t& a, hipStream_t st);
+int fpd_stem_wgrad_s2d_partials(const fpd_stem_t& a);
 int fpd_stem_wgrad_mfma_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_stem_wgrad_launch(const fpd_stem_t& a, hipStream_t st);
 int fpd_elementwise_launch(const fpd_ew_t& a, hipStream_t st);
@@ -315,7 +317,8 @@ int fpd_wgrad_num_partials(const fpd_wgrad_t* a) {
 int fpd_stem_wgrad_num_partials(const fpd_stem_t* a) {
     if (!a) return 0;
     int n = 0;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_stem_wgrad_mfma_partials(*a);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_stem_wgrad_s2d_partials(*a);
+    if (n == 0 && g_fpd_backend == FPD_BACKEND_MFMA) n = fpd_stem_wgrad_mfma_partials(*a);
     if (n == 0) n = fpd_stem_wgrad_partials(*a);
     return n;
 }
@@ -340,7 +343,8 @@ int fpd_stem_wgrad(const fpd_stem_t* a, fpd_stream_t stream) {
     FPD_REQUIRE(a->partial == nullptr || a->partial_stride >= (int64_t)a->K * 148, "stem wgrad: partial_stride %lld smaller than weight + bias",
                 (long long)a->partial_stride);
     int rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_wgrad_mfma_launch(*a, (hipStream_t)stream);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_wgrad_s2d_launch(*a, (hipStream_t)stream);
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_stem_wgrad_mfma_launch(*a, (hipStream_t)stream);
     if (rc == 1) rc = fpd_stem_wgrad_launch(*a, (hipStream_t)stream);
     return rc ? rc : check_launch();
 }

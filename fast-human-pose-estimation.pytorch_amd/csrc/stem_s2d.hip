@@ -256,6 +256,203 @@ __global__ __launch_bounds__(256) void stem_s2d_fwd_kernel(const fpd_stem_t a, c
 #undef S2_PUT
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem in the same space-to-depth form (K <= 32: the hourglass student; round 5):
+//     dW'[k][kr][ks][ch] = sum_pixels dy[p][q][k] * S[p + kr][q + ks][ch],      dw[k][r][s][c] = dW'[k][kr][ks][(dy*3 + c)*2 + dx]
+// for r = 2 kr + dy - 1 >= 0, s = 2 ks + dx - 1 >= 0; dbias[k] = sum dy.  It is the LAST weight gradient of a backward -- its
+// operand is the last tensor the chain produces -- so its duration is exposed in front of Adam (81 us as an im2col GEMM,
+// stem_wgrad_mfma).  Both operands stay pixel-major in LDS (the S ring of the forward kernel, the dy tile as it sits in HBM) and
+// reach the MFMA through transposing reads; an operand's 32 columns are two taps of 16 channels, (kr, ks) and (kr, ks + 2), which
+// are the SAME pixels shifted by two -- a per-lane address offset --, and the pair (ks + 1, ks + 3) is their funnel shift by one
+// pixel: 3 reads + 4 v_perm per tap row for 2 MFMAs.  4 waves split the eight 16-pixel k-steps of a tile, 8 accumulator tiles each;
+// fixed-order cross-wave sum through LDS at the end, one slab per block.
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef short s16x4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4s* lds_s16x4s_ptr;
+__device__ __forceinline__ u32x2s s2_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2s, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4s_ptr)(p)));
+}
+
+__global__ __launch_bounds__(256) void stem_s2d_wgrad_kernel(const fpd_stem_t a, const int logQ, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, P = a.P, Q = a.Q, H = a.H, W = a.W;       // K <= 32
+    const int rows = 128 >> logQ, QP = Q + 3, RING = 2 * rows + 3;
+    const unsigned RSs = (unsigned)QP * S2_PIXB, RINGB = (unsigned)RING * RSs;
+    unsigned char* sS = smem;                                        // [RING][QP][48 B]
+    unsigned char* sD = sS + RINGB;                                  // dy tile [128][32] bf16 (64-byte rows); the ring's over-reads end here
+    const float* __restrict__ x = a.x;
+    const bf16_t* __restrict__ dyp = reinterpret_cast<const bf16_t*>(a.dy);
+    auto wrap = [&](unsigned v) { return min(v, v - RINGB); };
+    const int t_beg = (int)((long long)blockIdx.x * ntiles / gridDim.x), t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+
+    for (int i = tid; i < RING * QP; i += 256) *reinterpret_cast<uint2*>(sS + (unsigned)i * S2_PIXB + 24) = make_uint2(0u, 0u);
+    for (int i = tid; i < 128 * 4; i += 256) *reinterpret_cast<uint4*>(sD + i * 16) = make_uint4(0, 0, 0, 0);      // columns >= K stay zero
+
+    auto s_row_store = [&](int R, int dc, int cc, float2 v) {
+        const unsigned slot = (unsigned)(R % RING);
+        *reinterpret_cast<unsigned*>(sS + slot * RSs + (unsigned)cc * S2_PIXB + dc * 4) = f2bf_pk(v.x, v.y);
+    };
+    auto s_load = [&](int n, int R, int dc, int cc) {
+        const int dy = dc >= 3 ? 1 : 0, c = dc - 3 * dy;
+        const int ih = 2 * R + dy - 4, iw = 2 * cc - 4;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        float2 v = *reinterpret_cast<const float2*>(x + ((size_t)(n * 3 + c) * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 2));
+        if (!ok) v = make_float2(0.f, 0.f);
+        return v;
+    };
+    auto full_load = [&](int n, int R0, int R1) {
+        const int per_row = 6 * QP, total = (R1 - R0) * per_row;
+        for (int base = 0; base < total; base += 8 * 256) {
+            float2 v[8];
+            int rl[8], dcv[8], ccv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = min(base + tid + i * 256, total - 1);
+                rl[i] = idx / per_row;
+                const int rem = idx - rl[i] * per_row;
+                dcv[i] = rem / QP; ccv[i] = rem - dcv[i] * QP;
+                v[i] = s_load(n, R0 + rl[i], dcv[i], ccv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (base + tid + i * 256 < total) s_row_store(R0 + rl[i], dcv[i], ccv[i], v[i]);
+        }
+    };
+    int v_rl[S2_NV], v_dc[S2_NV], v_cc[S2_NV];
+    const int per_row = 6 * QP, nnew = rows * per_row;
+#pragma unroll
+    for (int i = 0; i < S2_NV; ++i) {
+        const int idx = min(tid + i * 256, nnew - 1);
+        v_rl[i] = idx / per_row;
+        const int rem = idx - v_rl[i] * per_row;
+        v_dc[i] = rem / QP;
+        v_cc[i] = rem - v_dc[i] * QP;
+    }
+    float2 pv0, pv1, pv2, pv3;
+#define S2_PREF(i, PV, n_, R0_) PV = s_load(n_, (R0_) + v_rl[i], v_dc[i], v_cc[i]);
+#define S2_PUT(i, PV, R0_) if (tid + i * 256 < nnew) s_row_store((R0_) + v_rl[i], v_dc[i], v_cc[i], PV);
+    // dy tile: 128 pixels x K channels = 128 x (K / 8) 16-byte vectors, <= 2 per thread; LDS rows of 64 bytes
+    const int vpr = K >> 3;
+    const int dpx0 = tid / vpr, dcv0 = (tid - dpx0 * vpr) * 8, dpx1 = (tid + 256) / vpr, dcv1 = (tid + 256 - dpx1 * vpr) * 8;
+    const bool dok0 = tid < 128 * vpr, dok1 = tid + 256 < 128 * vpr;
+    uint4 rd0 = make_uint4(0, 0, 0, 0), rd1 = rd0;
+    auto d_load = [&](int t) {
+        const bf16_t* base = dyp + (size_t)t * 128 * K;
+        if (dok0) rd0 = *reinterpret_cast<const uint4*>(base + dpx0 * K + dcv0);
+        if (dok1) rd1 = *reinterpret_cast<const uint4*>(base + dpx1 * K + dcv1);
+    };
+    auto d_store = [&]() {
+        if (dok0) *reinterpret_cast<uint4*>(sD + dpx0 * 64 + dcv0 * 2) = rd0;
+        if (dok1) *reinterpret_cast<uint4*>(sD + dpx1 * 64 + dcv1 * 2) = rd1;
+    };
+
+    f32x16 acc[8];                                   // [kr][pair]: columns 0..15 = tap (kr, pair), 16..31 = tap (kr, pair + 2)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+    const unsigned bsel = (((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1)) ? 0x3f803f80u : 0u;
+    const u32x4s bones = {bsel, bsel, bsel, bsel};
+    const bool do_bias = a.dbias != nullptr;
+    // lane geometry of a transposing fragment read (mfma_frag.h): 16-lane group g, lane s: row 8 (g >> 1) + (s >> 2), column half g & 1
+    const int g = lane >> 4, s16 = lane & 15;
+    const unsigned fr_row = (unsigned)(8 * (g >> 1) + (s16 >> 2));
+    const unsigned a_off = fr_row * 64 + (unsigned)(16 * (g & 1) + 4 * (s16 & 3)) * 2;                       // dy tile: 32 columns = channels
+    const unsigned b_off = (fr_row + 2 * (g & 1)) * S2_PIXB + (unsigned)(4 * (s16 & 3)) * 2;                // S ring: column half = pixel shift + 2
+
+    int ring_n = -1, ring_hi = 0;
+    bool pref = false;
+    if (t_beg < t_end) d_load(t_beg);
+    for (int t = t_beg; t < t_end; ++t) {
+        const int g0 = t * rows, n = g0 / P, p0 = g0 - n * P;
+        __syncthreads();                                                   // previous tile's fragment reads are done
+        if (pref && n == ring_n && p0 + 3 == ring_hi) {
+            S2_PUT(0, pv0, ring_hi) S2_PUT(1, pv1, ring_hi) S2_PUT(2, pv2, ring_hi) S2_PUT(3, pv3, ring_hi)
+        } else {
+            full_load(n, p0, p0 + rows + 3);
+        }
+        d_store();
+        ring_n = n; ring_hi = p0 + rows + 3;
+        __syncthreads();
+        pref = false;
+        if (t + 1 < t_end) {
+            d_load(t + 1);
+            if (p0 + rows < P) {
+                S2_PREF(0, pv0, n, ring_hi) S2_PREF(1, pv1, n, ring_hi) S2_PREF(2, pv2, n, ring_hi) S2_PREF(3, pv3, n, ring_hi)
+                pref = true;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pix0 = (wave + 4 * h) * 16;                          // this wave's k-step: 16 pixels of one output row
+            const int ti = pix0 >> logQ, tj0 = pix0 & (Q - 1);
+            union { struct { u32x2s a, b; } hh; bf16x8 f; } ua;
+            ua.hh.a = s2_tr(sD + (unsigned)pix0 * 64 + a_off);
+            ua.hh.b = s2_tr(sD + (unsigned)pix0 * 64 + a_off + 4 * 64);
+            const bf16x8 af = ua.f;
+            const unsigned r0 = (unsigned)((p0 + ti) % RING) * RSs;
+            const unsigned col = (unsigned)tj0 * S2_PIXB + b_off;
+#pragma unroll
+            for (int kr = 0; kr < 4; ++kr) {
+                const unsigned char* base = sS + wrap(r0 + (unsigned)kr * RSs) + col;
+                const u32x2s lo = s2_tr(base), hi = s2_tr(base + 4 * S2_PIXB), nx = s2_tr(base + 8 * S2_PIXB);
+                const u32x4s b02 = {lo[0], lo[1], hi[0], hi[1]};
+                const u32x4s b13 = {__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(hi[0], lo[1], 16),
+                                    __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(nx[0], hi[1], 16)};
+                acc[2 * kr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b02), acc[2 * kr], 0, 0, 0);
+                acc[2 * kr + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b13), acc[2 * kr + 1], 0, 0, 0);
+            }
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bones), accb, 0, 0, 0);
+        }
+    }
+#undef S2_PREF
+#undef S2_PUT
+
+    // ---- flush: the four waves added in wave order, one tap row (two accumulator tiles) per pass, scattered into the dw layout ----
+    float* slab = a.partial != nullptr ? a.partial + (size_t)blockIdx.x * a.partial_stride : nullptr;
+    float* s_red = reinterpret_cast<float*>(smem);                      // [4 waves][2 tiles][16][64]
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr) {
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_red[((wave * 2 + t2) * 16 + e) * 64 + lane] = acc[2 * kr + t2][e];
+        __syncthreads();
+        for (int id = tid; id < 2 * 16 * 64; id += 256) {
+            const int t2 = id >> 10, e = (id >> 6) & 15, l = id & 63;
+            float sum = s_red[((0 * 2 + t2) * 16 + e) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum += s_red[((w * 2 + t2) * 16 + e) * 64 + l];
+            const int k = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), col = l & 31;
+            const int ks = t2 + 2 * (col >> 4), ch = col & 15, dx = ch & 1, dc = ch >> 1, dyy = dc >= 3 ? 1 : 0, c = dc - 3 * dyy;
+            const int r = 2 * kr + dyy - 1, sx = 2 * ks + dx - 1;
+            if (k < K && ch < 12 && r >= 0 && sx >= 0) {
+                const size_t idx = ((size_t)(k * 7 + r) * 7 + sx) * 3 + c;
+                if (slab != nullptr) slab[idx] = sum; else a.dw[idx] += sum;
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        if ((lane & 15) < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_red[wave * 32 + 16 * (lane & 15) + 4 * (lane >> 4) + e] = accb[e];
+        }
+        __syncthreads();
+        if (tid < K) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += s_red[w * 32 + tid];
+            if (slab != nullptr) slab[(size_t)K * 147 + tid] = tot; else a.dbias[tid] += tot;
+        }
+    }
+}
+
 }  // namespace
 
 // return 1 = not applicable (the caller falls through to stem_fwd_mfma / the direct kernels)
@@ -283,5 +480,37 @@ int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st) {
         if (int rc_ = cfg2.ensure(reinterpret_cast<const void*>(&stem_s2d_fwd_kernel<2>), lds)) return rc_;
         FPD_LAUNCH((stem_s2d_fwd_kernel<2>), dim3(blocks), dim3(256), lds, st, a, logQ, tiles);
     }
+    return 0;
+}
+
+static bool s2d_wgrad_ok(const fpd_stem_t& a, int& logQ, int& blocks) {
+    static const int enabled = getenv("FPD_STEM_S2D") ? atoi(getenv("FPD_STEM_S2D")) : 1;
+    if (!enabled || a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 32) return false;
+    if (a.Q > 128 || a.Q < 16 || (a.Q & (a.Q - 1)) != 0 || a.H != 2 * a.P || a.W != 2 * a.Q) return false;
+    logQ = 0;
+    while ((1 << logQ) < a.Q) ++logQ;
+    if (a.P % (128 >> logQ) != 0) return false;
+    const int tiles = a.N * a.P * a.Q / 128;
+    static const int cap = getenv("FPD_STEM_WGRAD_BLOCKS") ? atoi(getenv("FPD_STEM_WGRAD_BLOCKS")) : 256;
+    blocks = std::max(1, std::min(tiles, cap));
+    return true;
+}
+
+int fpd_stem_wgrad_s2d_partials(const fpd_stem_t& a) {
+    int logQ, blocks;
+    return s2d_wgrad_ok(a, logQ, blocks) ? blocks : 0;
+}
+
+// return 1 = not applicable
+int fpd_stem_wgrad_s2d_launch(const fpd_stem_t& a, hipStream_t st) {
+    int logQ, blocks;
+    if (!s2d_wgrad_ok(a, logQ, blocks)) return 1;
+    if (a.partial == nullptr) blocks = 1;                  // no slabs: one block adds straight into dw (small problems / tests)
+    const int rows = 128 >> logQ, ring = 2 * rows + 3;
+    const size_t lds = std::max((size_t)ring * (a.Q + 3) * S2_PIXB + (size_t)128 * 64 + 1024, (size_t)4 * 2 * 16 * 64 * sizeof(float));
+    const int tiles = a.N * a.P * a.Q / 128;
+    static LdsAttr cfg;
+    if (int rc_ = cfg.ensure(reinterpret_cast<const void*>(&stem_s2d_wgrad_kernel), lds)) return rc_;
+    FPD_LAUNCH(stem_s2d_wgrad_kernel, dim3(blocks), dim3(256), lds, st, a, logQ, tiles);
     return 0;
 }

@@ -41,6 +41,25 @@ def main():
         ms = l.fpd_event_elapsed_ms(e0, e1) / args.iters
         mb = (N * 3 * H * W * 4 + N * P * Q * K * 2) / 1e6
         print('%-20s %8.1f us   %6.1f MB algorithmic -> %6.0f GB/s' % (name, ms * 1e3, mb, mb / ms), flush=True)
+        if K <= 32:           # the weight gradient (student only: the teacher is frozen), with slabs as in a training plan
+            A.alloc('grad', K * 147 + K + 64)
+            A.t['act'].normal_(std=0.1)
+            wop = G.Op('stem_wgrad', image=img, dy=y, dw=G.Buf('grad', 0, (K, 7, 7, 3)), dbias=G.Buf('grad', K * 147, (K,)), dims=(N, H, W, K, P, Q))
+            low2 = E.Lowering(A, R.BF16)
+            low2.use_partials = True
+            lw = low2.op(wop)
+            low2.finish_partials()
+            plan2 = R.Plan()
+            plan2.add(*lw)
+            for _ in range(3):
+                plan2.run(0, 1, s)
+            torch.cuda.synchronize()
+            l.fpd_event_record(e0, s)
+            for _ in range(args.iters):
+                plan2.run(0, 1, s)
+            l.fpd_event_record(e1, s)
+            ms = l.fpd_event_elapsed_ms(e0, e1) / args.iters
+            print('%-20s %8.1f us   (weight gradient, %d slabs)' % (name, ms * 1e3, sum(r[4] for r in low2.partials.values())), flush=True)
 
 
 if __name__ == '__main__':
