@@ -11,4 +11,4 @@ timeout 900 python bench.py > $O/final_bench_line.json 2> $O/final_bench_err.txt
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $O/driver_style_line.json 2>/dev/null; python -c "import json;d=json.loads(open('$O/driver_style_line.json').read().strip().splitlines()[-1]);print('driver-style', d['ms_per_step'], d['value'])"
 timeout 600 python bench.py --config hrnet > $O/bench_line_hrnet.json 2> $O/hrnet_err.txt; python -c "import json;d=json.loads(open('$O/bench_line_hrnet.json').read().strip().splitlines()[-1]);print('hrnet', d['ms_per_step'], d['value'], d['config']['launches_per_step']['total'])"
 run() { timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-parity --no-phase-times 2> $O/err_$1.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'])"; }
-for i in 1 2 3; do run base_$i; FPD_HEAD_BLOCKS=128 run head128_$i; done
+for i in 1 2 3; do run base_$i; done
