@@ -73,16 +73,28 @@ __global__ __launch_bounds__(256) void loss_kernel(const fpd_loss_t a) {
 // image; a thread owns ONE 16-byte vector of joints of one pixel for all S stacks -- one vector load per map, one vector store
 // per gradient (the element-per-thread kernel above moves 2-byte words: 65 us for the 2 M elements of the benchmark, on the
 // student's critical chain).  Same arithmetic per element, same per-block sums (fixed order), same grid-aligned loss terms.
+// Round 5: a block walks `tpb` tiles of its image and adds ONE pair of loss terms at the end.  With a block per tile the 2 x 1 024
+// fp64 atomics of the benchmark shape all hit the same two addresses and serialise in the L2 at ~20 ns each: 36 us for 42 MB of
+// traffic, between the student's forward and backward where nothing else of the chain can run (r05 trace; requesting all maps of a
+// pixel up front changed nothing).
 template <typename T>
-__global__ __launch_bounds__(256) void loss_vec_kernel(const fpd_loss_t a) {
+__global__ __launch_bounds__(256) void loss_vec_kernel(const fpd_loss_t a, const int tpb) {
     constexpr int VEC = DT<T>::VEC, PT = 128;
     __shared__ float s_tg[PT * 33];       // [pixel][joint], J <= 32, padded rows
     __shared__ double s_acc[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int J = a.J, HW = a.H * a.W;
-    const int tiles_per_img = (HW + PT - 1) / PT;
-    const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * PT;
+    const int tiles_per_img = (HW + PT - 1) / PT, bpi = (tiles_per_img + tpb - 1) / tpb;       // blocks per image
+    const int b = blockIdx.x / bpi, tile0 = (blockIdx.x - b * bpi) * tpb;
     const int LDJ = J + 1;
+    const double cnt = (double)a.B * J * HW;
+    const float gs = a.grad_scale / (float)cnt;
+    const T* tch = reinterpret_cast<const T*>(a.teacher);
+    const int VPP = J / VEC;                     // vectors per pixel
+    float pose = 0.f, kd = 0.f;
+    for (int tt = tile0; tt < min(tile0 + tpb, tiles_per_img); ++tt) {
+    const int p0 = tt * PT;
+    __syncthreads();                             // the previous tile's targets have been read
     if (a.target_nchw) {
         for (int i = tid; i < J * PT; i += 256) {
             const int j = i / PT, p = i - j * PT;
@@ -95,11 +107,6 @@ __global__ __launch_bounds__(256) void loss_vec_kernel(const fpd_loss_t a) {
         }
     }
     __syncthreads();
-    const double cnt = (double)a.B * J * HW;
-    const float gs = a.grad_scale / (float)cnt;
-    const T* tch = reinterpret_cast<const T*>(a.teacher);
-    const int VPP = J / VEC;                     // vectors per pixel
-    float pose = 0.f, kd = 0.f;
     for (int v = tid; v < PT * VPP; v += 256) {
         const int p = v / VPP, j0 = (v - p * VPP) * VEC;
         if (p0 + p >= HW) continue;
@@ -126,6 +133,7 @@ __global__ __launch_bounds__(256) void loss_vec_kernel(const fpd_loss_t a) {
             if (a.dout[s] != nullptr) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.dout[s]) + off) = DT<T>::pack(d);
         }
     }
+    }                                            // tiles of this block
     const double dp = wave_sum_d((double)pose), dk = wave_sum_d((double)kd);
     if (lane == 0) { s_acc[0][wave] = dp; s_acc[1][wave] = dk; }
     __syncthreads();
@@ -250,11 +258,15 @@ int fpd_loss_launch(const fpd_loss_t& a, hipStream_t st) {
     bool aligned = a.J % vec == 0 && ((uintptr_t)a.teacher & 15) == 0;
     for (int s = 0; s < a.S; ++s) aligned = aligned && ((uintptr_t)a.out[s] & 15) == 0 && ((uintptr_t)a.dout[s] & 15) == 0;
     if (aligned) {                               // 16-byte vectors of joints (the benchmark's J = 16)
-        const int vt = a.B * cdiv(a.H * a.W, 128);
+        // <= 256 blocks (= 512 same-address atomics), tiles of one image per block
+        const int tpi = cdiv(a.H * a.W, 128);
+        int tpb = 1;
+        while (a.B * cdiv(tpi, tpb) > 256 && tpb < tpi) ++tpb;
+        const int vt = a.B * cdiv(tpi, tpb);
         if (a.dtype == FPD_BF16)
-            FPD_LAUNCH((loss_vec_kernel<bf16_t>), dim3(vt), dim3(256), 0, st, a);
+            FPD_LAUNCH((loss_vec_kernel<bf16_t>), dim3(vt), dim3(256), 0, st, a, tpb);
         else
-            FPD_LAUNCH((loss_vec_kernel<float>), dim3(vt), dim3(256), 0, st, a);
+            FPD_LAUNCH((loss_vec_kernel<float>), dim3(vt), dim3(256), 0, st, a, tpb);
         return 0;
     }
     const int tiles = a.B * cdiv(a.H * a.W, 64);
