@@ -5,6 +5,7 @@
 // Replaces F.max_pool2d / nn.Upsample / nn.BatchNorm2d / nn.ReLU and their autograd in
 // /root/reference/lib/models/hourglass.py:80-92,172-177.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -70,11 +71,14 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc1[j] = 0.0; acc2[j] = 0.0; }
 
-    const T* x = reinterpret_cast<const T*>(a.x);
-    const T* x2 = reinterpret_cast<const T*>(a.x2);
-    const T* dy = reinterpret_cast<const T*>(a.dy);
-    const T* add = reinterpret_cast<const T*>(a.add);
-    T* y = reinterpret_cast<T*>(a.y);
+    // (restrict: an output may alias an input IN PLACE -- the same thread reads a pixel's vectors before it writes them and no
+    // other thread or iteration touches them -- so letting the loads of the next pixel pass the stores of this one is safe, and it
+    // is what puts two pixels' loads in flight per thread in the loop below)
+    const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ x2 = reinterpret_cast<const T*>(a.x2);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+    const T* __restrict__ add = reinterpret_cast<const T*>(a.add);
+    T* __restrict__ y = reinterpret_cast<T*>(a.y);
     const bool do_stats = STATS ? (a.out_stats != nullptr) : BSTATS;
 
     if (active) {
@@ -90,11 +94,16 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
                 float v[VEC], g[VEC], mk[VEC];
                 ldv<T>(x + (size_t)pix * C + cv, v);
                 ldv<T>(dy + (size_t)pix * C + cv, g);
-                if (x2 != nullptr) ldv<T>(x2 + (size_t)pix * C + cv, mk);     // mask source: forward output of a relu(sum) op
+                // mk = what the ReLU mask is taken from (one uniform branch per pixel; per element it compiled to a branch each)
+                if (x2 != nullptr) {
+                    ldv<T>(x2 + (size_t)pix * C + cv, mk);                    // forward output of a relu(sum) op
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) mk[j] = a.bn.relu ? fmaf(v[j], s_t0[cv + j], s_t1[cv + j]) : 1.f;
+                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float z = x2 != nullptr ? mk[j] : fmaf(v[j], s_t0[cv + j], s_t1[cv + j]);
-                    o[j] = ((x2 == nullptr && !a.bn.relu) || z > 0.f) ? g[j] : 0.f;
+                    o[j] = mk[j] > 0.f ? g[j] : 0.f;
                     const double r = (double)DT<T>::rnd(o[j]);
                     acc1[j] += r;
                     acc2[j] += r * (double)((v[j] - s_t2[cv + j]) * s_t3[cv + j]);
@@ -206,6 +215,17 @@ __global__ __launch_bounds__(256) void ew_pair_kernel(const fpd_ew_t a, const fp
     else ew_body<T, OP>(a, (int)blockIdx.x - gb, ga);
 }
 
+// grid cap of the ops that end in statistics atomics (FPD_EW_STATS_BLOCKS)
+static int ew_stats_blocks() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("FPD_EW_STATS_BLOCKS");
+        v = e ? atoi(e) : 512;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 template <typename T, int OP>
 int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     constexpr int VEC = DT<T>::VEC;
@@ -216,7 +236,7 @@ int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     // adds into the SAME [2][C] buffer and same-address device atomics serialise (~12 ns each)
     const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
                                                                                                    : OP == FPD_EW_BNRELU_BWD_R;
-    const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
+    const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? ew_stats_blocks() : 2048));
     FPD_LAUNCH((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
@@ -229,7 +249,7 @@ int ew_grid(const fpd_ew_t& a) {
     const int npix = a.N * (half ? a.H / 2 : a.H) * (half ? a.W / 2 : a.W);
     const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
                                                                                                    : OP == FPD_EW_BNRELU_BWD_R;
-    return std::max(1, std::min(cdiv(npix, PB), stats ? 512 : 2048));
+    return std::max(1, std::min(cdiv(npix, PB), stats ? ew_stats_blocks() : 2048));
 }
 
 template <typename T>
