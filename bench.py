@@ -30,7 +30,10 @@ sys.path.insert(0, ROOT)
 # Before the HIP runtime loads (it is part of torch): a step keeps three streams busy (teacher, student chain, weight
 # gradients) and RCCL adds its own; with ROCm's default of 4 hardware queues two of the hot streams can end up sharing
 # one and serialise (measured: 14.4 -> 17.8 ms/step as soon as the process group exists).  See DESIGN.md section 4.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# With the RCCL process group in the process (WORLD_SIZE > 1 or --force-dist) 6 queues: 5 streams are active on the default
+# data-parallel path, a 6th with FPD_ALLREDUCE_BUCKETS=1, and at 8 queues that 6th serialises every lane (26.7 ms/step, r03); the
+# default path itself is 0.03 (r03) - 0.08 ms/step (r05, three interleaved pairs: 9.80 vs 9.72; plain step 9.69) faster at 6.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6' if (int(os.environ.get('WORLD_SIZE', '1')) > 1 or '--force-dist' in sys.argv) else '8')
 
 import torch  # noqa: E402
 

@@ -19,7 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before torch loads the HIP runtime; see bench.py / DESIGN.md section 4
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '8')      # before torch loads the HIP runtime; see bench.py / DESIGN.md section 4
 
 import torch  # noqa: E402
 import torch.utils.data  # noqa: E402
