@@ -33,7 +33,18 @@ sys.path.insert(0, ROOT)
 # With the RCCL process group in the process (WORLD_SIZE > 1 or --force-dist) 6 queues: 5 streams are active on the default
 # data-parallel path, a 6th with FPD_ALLREDUCE_BUCKETS=1, and at 8 queues that 6th serialises every lane (26.7 ms/step, r03); the
 # default path itself is 0.03 (r03) - 0.08 ms/step (r05, three interleaved pairs: 9.80 vs 9.72; plain step 9.69) faster at 6.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '6' if (int(os.environ.get('WORLD_SIZE', '1')) > 1 or '--force-dist' in sys.argv) else '8')
+def _dist_run():
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or '--force-dist' in sys.argv:
+        return True
+    for i, t in enumerate(sys.argv):            # `python bench.py --gpus N` re-launches itself under torch.distributed.run: the children inherit this
+        if t == '--gpus' and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit() and int(sys.argv[i + 1]) > 1:
+            return True
+        if t.startswith('--gpus=') and t[7:].isdigit() and int(t[7:]) > 1:
+            return True
+    return False
+
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6' if _dist_run() else '8')
 
 import torch  # noqa: E402
 

@@ -112,3 +112,27 @@ def test_strict_alignment_refuses_count_drift_and_geometry_mismatch():
     assert bad2 == 1 and len(tags2) == len(want) - 1
     with pytest.raises(ValueError):
         trace_align.align(log, wrong, strict=True)
+
+
+@pytest.mark.parametrize('argv,env,want', [
+    ([], {}, '8'),
+    (['--gpus', '1'], {}, '8'),
+    (['--force-dist'], {}, '6'),
+    (['--gpus', '4'], {}, '6'),                      # re-launches itself under torch.distributed.run: the ranks inherit the value
+    (['--gpus=2'], {}, '6'),
+    (['--gpus', '1'], {'WORLD_SIZE': '8'}, '6'),     # a rank started by the driver's launcher
+    ([], {'GPU_MAX_HW_QUEUES': '4'}, '4'),           # an explicit setting always wins
+])
+def test_bench_picks_the_hardware_queue_count_before_torch_loads(argv, env, want):
+    """bench.py sets GPU_MAX_HW_QUEUES before the HIP runtime loads: 8 for the plain step, 6 whenever the RCCL process group will
+    exist (profiles/r05_late_ab.txt calls 31-32)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.argv = ['bench.py'] + %r; os.environ.pop('GPU_MAX_HW_QUEUES', None); os.environ.pop('WORLD_SIZE', None); "
+            "os.environ.update(%r); p = %r; src = open(p).read(); src = src[:src.index('import torch')]; "
+            "exec(compile(src, p, 'exec'), {'__file__': p, '__name__': 'bench_head'}); print(os.environ['GPU_MAX_HW_QUEUES'])"
+            % (argv, env, os.path.join(root, 'bench.py')))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert out.stdout.strip() == want
