@@ -136,3 +136,38 @@ def test_bench_picks_the_hardware_queue_count_before_torch_loads(argv, env, want
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr[-400:]
     assert out.stdout.strip() == want
+
+
+def test_isa_report_splits_a_listing_into_kernels_and_basic_blocks():
+    """tools/isa_report.py (static instruction counts: the issue-bound model of DESIGN.md section 8 makes them a time estimate)."""
+    import isa_report
+    listing = '''\t.text
+_ZN1a6kernelEv:                          ; @_ZN1a6kernelEv
+; %bb.0:
+\ts_load_dwordx2 s[0:1], s[4:5], 0x0
+\tv_mov_b32_e32 v1, 0
+.LBB0_1:                                ; =>This Inner Loop Header
+\tds_read_b128 v[2:5], v1
+\tglobal_load_dwordx4 v[6:9], v1, s[0:1]
+\tv_mfma_f32_32x32x16_bf16 v[10:25], v[2:5], v[6:9], v[10:25]
+\tv_mfma_f32_32x32x16_bf16 v[10:25], v[2:5], v[6:9], v[10:25]
+\ts_cbranch_scc1 .LBB0_1
+; %bb.2:
+\ts_and_saveexec_b64 s[2:3], vcc
+\ts_cbranch_execz .LBB0_4
+.LBB0_4:
+\ts_endpgm
+.Lfunc_end0:
+\t.size\t_ZN1a6kernelEv, .Lfunc_end0-_ZN1a6kernelEv
+_ZN1a5otherEv:
+\ts_endpgm
+.Lfunc_end1:
+'''.split('\n')
+    ks = isa_report.kernels(listing)
+    assert [n for n, _ in ks] == ['_ZN1a6kernelEv', '_ZN1a5otherEv']
+    blocks = ks[0][1]
+    assert [lab for lab, _ in blocks] == ['entry', '.LBB0_1', '.LBB0_4']
+    assert blocks[1][1] == ['ds_read_b128', 'global_load_dwordx4', 'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_bf16', 's_cbranch_scc1',
+                            's_and_saveexec_b64', 's_cbranch_execz']
+    s = isa_report.summary(blocks)
+    assert s == {'instructions': 10, 'mfma': 2, 'blocks': 3, 'branches': 2, 'saveexec': 1, 'lds_reads': 1, 'global_loads': 1}
