@@ -12,6 +12,12 @@
 int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_c1_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_c1_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
+int fpd_conv_c1_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b);
+int fpd_conv_c1_option(int which, int value);
+int fpd_conv_c1_wgrad_partials(const fpd_conv_t& a);
+int fpd_conv_c1_pair_wgrad_partials(const fpd_conv_t& a, const fpd_conv_t& b, int* na, int* nb);
 int fpd_conv_pp_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_conv_pp_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b);
 int fpd_conv_tile_fold_ok(const fpd_conv_t& a);
@@ -125,6 +131,9 @@ int fpd_set_option(const char* name, int32_t value) {
     FPD_REQUIRE(name, "set_option: null name");
     if (!strcmp(name, "conv_pp")) return fpd_conv_pp_option(0, value);
     if (!strcmp(name, "conv_pp_blocks")) return fpd_conv_pp_option(1, value);
+    if (!strcmp(name, "conv_c1")) return fpd_conv_c1_option(0, value);
+    if (!strcmp(name, "conv_c1_blocks")) return fpd_conv_c1_option(1, value);
+    if (!strcmp(name, "conv_c1_launches")) return fpd_conv_c1_option(2, value);      // (read-only: launches served so far)
     if (!strcmp(name, "wgrad_tile_only")) { g_wgrad_tile_only = value; return 0; }
     return fpd_fail(-2, "set_option: unknown option '%s'", name);
 }
@@ -153,7 +162,8 @@ static int validate_conv(const fpd_conv_t* a) {
 
 static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     int rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent kernel
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c1_launch(*a, st);      // big maps, 1x1: streaming kernel
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent kernel
     FPD_REQUIRE(rc != 1 || a->wg_partial == nullptr, "conv: a fused weight gradient (wg_partial) needs the persistent kernel; "
                 "fpd_conv_fused_wgrad_partials() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_launch(*a, st);
@@ -174,11 +184,12 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
 
 int fpd_conv_fold_supported(const fpd_conv_t* a) {
     if (!a || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(a) != 0) return 0;
-    return (fpd_conv_pp_fold_ok(*a, nullptr) || fpd_conv_tile_fold_ok(*a)) ? 1 : 0;
+    return (fpd_conv_c1_fold_ok(*a, nullptr) || fpd_conv_pp_fold_ok(*a, nullptr) || fpd_conv_tile_fold_ok(*a)) ? 1 : 0;
 }
 int fpd_conv_pair_fold_supported(const fpd_conv_pair_t* p) {
     if (!p || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(&p->a) != 0 || validate_conv(&p->b) != 0) return 0;
-    // the dispatch order of fpd_conv_forward_pair(): persistent pair, halo-tile pair, two single launches
+    // the dispatch order of fpd_conv_forward_pair(): streaming pair, persistent pair, halo-tile pair, two single launches
+    if (fpd_conv_c1_fold_ok(p->a, &p->b)) return 1;
     if (fpd_conv_pp_fold_ok(p->a, &p->b)) return 1;
     const int r = fpd_conv_tile_pair_fold_ok(p->a, p->b);
     if (r >= 0) return r;
@@ -187,14 +198,15 @@ int fpd_conv_pair_fold_supported(const fpd_conv_pair_t* p) {
 
 int fpd_conv_fused_wgrad_partials(const fpd_conv_t* a) {
     if (!a || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(a) != 0) return 0;
-    return fpd_conv_pp_wgrad_partials(*a);
+    const int n = fpd_conv_c1_wgrad_partials(*a);      // (-1: the streaming kernel does not take this launch)
+    return n >= 0 ? n : fpd_conv_pp_wgrad_partials(*a);
 }
 int fpd_conv_pair_fused_wgrad_partials(const fpd_conv_pair_t* p, int32_t* n_a, int32_t* n_b) {
     FPD_REQUIRE(p && n_a && n_b, "conv_pair_fused_wgrad_partials: null pointer");
     *n_a = *n_b = 0;
     if (g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(&p->a) != 0 || validate_conv(&p->b) != 0) return 0;
     int na = 0, nb = 0;
-    fpd_conv_pp_pair_wgrad_partials(p->a, p->b, &na, &nb);
+    if (fpd_conv_c1_pair_wgrad_partials(p->a, p->b, &na, &nb) < 0) fpd_conv_pp_pair_wgrad_partials(p->a, p->b, &na, &nb);
     *n_a = na; *n_b = nb;
     return 0;
 }
@@ -227,7 +239,8 @@ int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
-    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
+    if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c1_pair_launch(p->a, p->b, st);
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
     FPD_REQUIRE(rc != 1 || (p->a.wg_partial == nullptr && p->b.wg_partial == nullptr),
                 "conv_pair: fused weight gradients need the persistent kernel; fpd_conv_pair_fused_wgrad_partials() reports 0 for this launch");
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_tile_pair_launch(p->a, p->b, st);

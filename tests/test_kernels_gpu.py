@@ -68,12 +68,25 @@ class Bench:
             # the persistent ping-pong convolution (csrc/conv_pp.hip) forced for every in-domain bf16 shape; ('pp', n): n blocks,
             # so that a block owns many tiles (uneven ranges, ragged last tiles, long ping-pong loops) even on small tensors
             blocks = backend[1] if isinstance(backend, tuple) else 256
-            pm, pb = R.set_option('conv_pp', 2), R.set_option('conv_pp_blocks', blocks)
+            pm, pb, cm = R.set_option('conv_pp', 2), R.set_option('conv_pp_blocks', blocks), R.set_option('conv_c1', 0)
             try:
                 return self.run(ops, 0, partials)
             finally:
                 R.set_option('conv_pp', pm)
                 R.set_option('conv_pp_blocks', pb)
+                R.set_option('conv_c1', cm)
+        if backend == 'c1' or (isinstance(backend, tuple) and backend[0] == 'c1'):
+            # the streaming 1x1 convolution (csrc/conv_c1.hip) forced for every in-domain shape; ('c1', n): n blocks, so that a
+            # block owns several rounds (uneven ranges, a ragged last round) even on small tensors.  self.n_c1 = launches it served
+            blocks = backend[1] if isinstance(backend, tuple) else 256
+            cm, cb = R.set_option('conv_c1', 2), R.set_option('conv_c1_blocks', blocks)
+            n0 = R.set_option('conv_c1_launches', 0)
+            try:
+                return self.run(ops, 0, partials)
+            finally:
+                self.n_c1 = R.set_option('conv_c1_launches', 0) - n0
+                R.set_option('conv_c1', cm)
+                R.set_option('conv_c1_blocks', cb)
         if partials:                         # slab reduction of all weight gradients of the list (one gradient bucket)
             wg = [o for o in ops if o.kind == 'wgrad']
             ops = list(ops) + [G.Op('wreduce', bucket=0, wgrads=wg, bufs=[x for w in wg for x in (w.dw, w.dbias) if x is not None])]
