@@ -60,7 +60,7 @@ struct C1Geo {
     static constexpr int PXA = C * 2 + 16, PXO = K * 2 + 16;     // pixel pitch of the operand / output tile (bytes)
     static constexpr int TILE_A = 32 * PXA, TILE_O = 32 * PXO;
     static constexpr int WAVE_LDS = BWD ? TILE_A + TILE_O : (TILE_A > TILE_O ? TILE_A : TILE_O);
-    static constexpr int FLUSH = C1_NW * 64 * 16 * 4 + C1_NW * K * 4;      // statistics records + common shifts
+    static constexpr int FLUSH = C1_NW * 64 * 16 * 4 + C1_NW * K * 4 + 8 * 2 * K * 8;      // statistics records + common shifts + partial sums
     static constexpr int REGION = C1_NW * WAVE_LDS > FLUSH ? C1_NW * WAVE_LDS : FLUSH;
     static constexpr int TABLES = (2 * C + (BWD ? 3 * C + 4 * K : 0) + K) * 4;
     static constexpr int LDS = TABLES + K * C * 2 + REGION;
@@ -75,6 +75,12 @@ struct C1Geo {
 // (and no arithmetic either: hipcc fills the shadow of the MFMAs with the NEXT phase's unpacking of every vector in flight,
 //  which costs more registers than the kernel has; the other wave of the SIMD is what runs beside the matrix pipe)
 #define C1_PHASE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+#ifdef FPD_C1_TIMING      // probe build only: cycle stamps of waves 0 and 7 of two blocks at the phase boundaries, printed by the kernel
+#define C1_STAMP() do { if (lane == 0 && (wave == 0 || wave == 7) && c1_ns < 40) c1_stamp[(wave ? 40 : 0) + c1_ns++] = clock64(); } while (0)
+#else
+#define C1_STAMP() do { } while (0)
+#endif
 
 template <int C, int K, bool BWD, bool FOLD, bool WG, bool RES>
 __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const int nblk) {
@@ -114,6 +120,11 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
     const bool want_stats = BWD || a.out_stats != nullptr;
     const bool wg = WG && a.wg_partial != nullptr;
     const bool wg_bias = wg && a.wg_bias;
+#ifdef FPD_C1_TIMING
+    long long* c1_stamp = reinterpret_cast<long long*>(smem + G::LDS);      // [2][40] behind everything (the probe build asks for 1 KB more)
+    int c1_ns = 0;
+#endif
+    C1_STAMP();
 
     // ---- prologue: the table chains (loads -> fp64 -> LDS) on different waves, requested before the long loads ----
     BnRaw braw;
@@ -154,11 +165,9 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
         for (int i = 0; i < NK; ++i) rr[i] = pr[i * 64];
     };
     int tile = r_beg * C1_NW + wave;
-    if (r_beg < r_end && tile < ntile) {
-        load_x(tile);
-        if constexpr (BWD || has_res) load_r(tile);
-    }
     {
+        // requested in the order they are needed: tables (above), weights -- the first barrier waits for both --, then the
+        // first tile (100+ KB per block: at the chip's ~12 bytes per cycle and CU it takes 6-11 k cycles to arrive; stamps)
         constexpr int NWV = (K * CV + 511) / 512;         // weight vectors per thread
         uint4 rw[NWV];
 #pragma unroll
@@ -166,6 +175,14 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
             const int v = tid + i * 512;
             rw[i] = make_uint4(0, 0, 0, 0);
             if (v < K * CV) rw[i] = *reinterpret_cast<const uint4*>(w + (size_t)v * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // (unconditionally, a wave without a tile re-reads the last one: behind a branch hipcc waits for EVERY load in
+            //  flight -- vmcnt(0) -- before the weights go to the LDS, i.e. the first barrier waited for the whole first tile)
+            const int t0 = min(tile, ntile - 1);
+            load_x(t0);
+            if constexpr (BWD || has_res) load_r(t0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (r_bn) {
@@ -205,7 +222,9 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
             }
         }
     }
+    C1_STAMP();
     __syncthreads();                                      // tables + weights visible
+    C1_STAMP();
 
     // ---- per-lane constants: the 8 channels of this lane's operand / output chunk ----
     const int cch = lane % CV, kch = lane % KV;           // chunk of the operand / output pixel this lane always holds
@@ -356,25 +375,50 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
         }
     };
 
-    // ---- 5. WG: this wave's tiles of dW over the 256 pixels of the round (dy^T and a(u) through transposing reads) ----
+    // ---- 5. WG: this wave's tiles of dW over the 256 pixels of the round (dy^T and a(u) through transposing reads).  A full
+    //         round is unrolled with the fragments of tile s + 1 requested before the products of tile s (stamps of the
+    //         rolled loop: 5-6.7 k cycles per round for 16-32 MFMAs -- every pair of tiles waited for its LDS reads) ----
+    auto wg_frags = [&](const int s, bf16x8 (&af)[2][WG ? G::NTW : 1], bf16x8 (&bfr)[2][WG ? G::NTW : 1]) {
+        const bf16_t* dyT = reinterpret_cast<const bf16_t*>(sT + s * G::WAVE_LDS);
+        const bf16_t* aT = reinterpret_cast<const bf16_t*>(sT + s * G::WAVE_LDS + G::TILE_A);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < (WG ? G::NTW : 1); ++j) {
+                const int tw = wave + C1_NW * j, ci = tw / KT, ko = tw % KT;
+                af[h][j] = tr_frag_bf16(dyT, PXA / 2, h * 16, ci * 32, lane);
+                bfr[h][j] = tr_frag_bf16(aT, PXO / 2, h * 16, ko * 32, lane);
+            }
+        }
+    };
     auto wg_round = [&](const int round, auto biasc) {
         constexpr bool BIAS = decltype(biasc)::value;      // this wave owns tiles with ko == 0: the bias gradient rides along
         const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
-#pragma unroll 2
-        for (int s = 0; s < C1_NW; ++s) {
-            if (round * C1_NW + s < ntile) {
-                const bf16_t* dyT = reinterpret_cast<const bf16_t*>(sT + s * G::WAVE_LDS);
-                const bf16_t* aT = reinterpret_cast<const bf16_t*>(sT + s * G::WAVE_LDS + G::TILE_A);
+        bf16x8 af[2][2][WG ? G::NTW : 1], bfr[2][2][WG ? G::NTW : 1];      // [buffer][pixel half][tile]
+        auto mult = [&](const int b) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int j = 0; j < (WG ? G::NTW : 1); ++j) {
-                        const int tw = wave + C1_NW * j, ci = tw / KT, ko = tw % KT;
-                        const bf16x8 af = tr_frag_bf16(dyT, PXA / 2, h * 16, ci * 32, lane);
-                        const bf16x8 bfr = tr_frag_bf16(aT, PXO / 2, h * 16, ko * 32, lane);
-                        wacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, wacc[j], 0, 0, 0);
-                        if constexpr (BIAS) bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, bacc[j], 0, 0, 0);
-                    }
+                for (int j = 0; j < (WG ? G::NTW : 1); ++j) {
+                    wacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[b][h][j], bfr[b][h][j], wacc[j], 0, 0, 0);
+                    if constexpr (BIAS) bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[b][h][j], ones, bacc[j], 0, 0, 0);
+                }
+            }
+        };
+        if (round * C1_NW + C1_NW <= ntile) {
+            wg_frags(0, af[0], bfr[0]);
+#pragma unroll
+            for (int s = 0; s < C1_NW; ++s) {
+                if (s + 1 < C1_NW) wg_frags(s + 1, af[(s + 1) & 1], bfr[(s + 1) & 1]);
+                mult(s & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < C1_NW; ++s) {
+                if (round * C1_NW + s < ntile) {
+                    wg_frags(s, af[0], bfr[0]);
+                    mult(0);
                 }
             }
         }
@@ -392,6 +436,7 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
             else stage(tile, std::integral_constant<int, 0>{});
             if (pf) load_x(tile + C1_NW);                 // the next tile's vectors take the registers over
             C1_PHASE();
+            C1_STAMP();
             // ---- 2. the products: D[k][px] = sum_c W[k][c] * opnd[px][c]; a lane gets 4 consecutive channels of pixel l31 ----
             bf16x8 bf[KS];
 #pragma unroll
@@ -425,9 +470,11 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
             }
             if constexpr (!BWD && has_res) { if (pf) load_r(tile + C1_NW); }
             C1_PHASE();
+            C1_STAMP();
             if (want_stats) perchan(tile, first, std::true_type{}); else perchan(tile, first, std::false_type{});
             if (BWD && pf) load_r(tile + C1_NW);
             C1_PHASE();
+            C1_STAMP();
             first = false;
         }
         if (WG) {
@@ -437,8 +484,10 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
                 if (wg_bias && (wave % KT) == 0) wg_round(round, std::true_type{}); else wg_round(round, std::false_type{});
             }
             __syncthreads();                              // tiles free for the next round
+            C1_STAMP();
         }
     }
+    C1_STAMP();
 
     // ---- WG: this block's slab -- every wave stores the tiles of dW it owns (fpd_wgrad_reduce adds the slabs in order) ----
     if (WG && wg) {
@@ -472,31 +521,67 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
         }
         __syncthreads();
         fpd_stat_t* st = BWD ? a.epi_stats : a.out_stats;
-        if (tid < 2 * K) {
-            const int ch = tid % K, which = tid / K;      // which: 0 = first sum, 1 = second
+        // stage A (all threads): thread (part, which, ch) sums the records of NPW waves in a fixed order in fp64 and un-shifts
+        // them; stage B: the parts in order, one exact pair of limbs per (sum, channel) out.  (One thread per sum over all
+        // eight waves took 6.4 k cycles at the end of every block: stamps, round 6.)
+        constexpr int NPART = 512 / (2 * K) > C1_NW ? C1_NW : 512 / (2 * K);      // 2 (K = 128), 4 (K = 64), 8 (K = 32)
+        constexpr int NPW = C1_NW / NPART;
+        double* s_part = reinterpret_cast<double*>(shf + C1_NW * K);             // [NPART][2 K]
+        {
+            const int part = tid / (2 * K), rem = tid % (2 * K);
+            const int ch = rem % K, which = rem / K;      // which: 0 = first sum, 1 = second
             const int chunk = ch >> 3, e = ch & 7;
-            double tot = 0.0;
-#pragma unroll 1
-            for (int wv = 0; wv < C1_NW; ++wv) {
-                // tiles wave wv has processed: rounds r of this block with r * 8 + wv < ntile
-                const int last = (ntile - 1 - wv) >= 0 ? (ntile - 1 - wv) / C1_NW : -1;
-                const int hi = min(r_end - 1, last);
-                const int nt = hi >= r_beg ? hi - r_beg + 1 : 0;
-                double t1 = 0.0, t2 = 0.0;
-                for (int j = 0; j < 64 / KV; ++j) {
-                    const float* rp = rec + (wv * 64 + chunk + KV * j) * 16;
-                    t1 += (double)rp[e];
-                    t2 += (double)rp[8 + e];
+            if (part < NPART) {
+                double tot = 0.0;
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) {
+                    const int wv = part * NPW + q;
+                    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 64 / KV; ++jj) {
+                        const float* rp = rec + (wv * 64 + chunk + KV * jj) * 16;
+                        t1 += (double)rp[e];
+                        t2 += (double)rp[8 + e];
+                    }
+                    if (BWD) tot += which ? t2 : t1;
+                    else {
+                        // tiles wave wv has processed: rounds r of this block with r * 8 + wv < ntile
+                        const int last = (ntile - 1 - wv) >= 0 ? (ntile - 1 - wv) / C1_NW : -1;
+                        const int hi = min(r_end - 1, last);
+                        const int nt = hi >= r_beg ? hi - r_beg + 1 : 0;
+                        const double c = (double)shf[wv * K + ch], nn = 32.0 * nt;
+                        tot += which ? (t2 + 2.0 * c * t1 + nn * c * c) : (t1 + nn * c);
+                    }
                 }
-                if (BWD) tot += which ? t2 : t1;
-                else {
-                    const double c = (double)shf[wv * K + ch], n = 32.0 * nt;
-                    tot += which ? (t2 + 2.0 * c * t1 + n * c * c) : (t1 + n * c);
-                }
+                s_part[part * 2 * K + rem] = tot;
             }
-            stat_atomic_add(st, K, which, ch, tot);
+        }
+        __syncthreads();
+        if (tid < 2 * K) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < NPART; ++q) tot += s_part[q * 2 * K + tid];
+            stat_atomic_add(st, K, tid / K, tid % K, tot);
         }
     }
+#ifdef FPD_C1_TIMING
+    C1_STAMP();
+    if (lane == 0 && (wave == 0 || wave == 7)) c1_stamp[(wave ? 40 : 0) + 39] = c1_ns;
+    __syncthreads();
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 1)) {
+        // entry | tables + weights stored | barrier | per tile: staged (+ next requested), products + finish, per-channel + stores (WG: + round) | loop end | flush
+        // (one printf per row: concurrent printfs interleave)
+        for (int wv = 0; wv < 2; ++wv) {
+            const long long* sp = c1_stamp + wv * 40;
+            const long long t0 = c1_stamp[0];
+            long long d[16];
+            for (int q = 0; q < 16; ++q) d[q] = q < (int)sp[39] ? sp[q] - t0 : -1;
+            printf("conv_c1 C=%d K=%d bwd %d fold %d wg %d blk %d wave %d rounds %d: %lld %lld %lld | %lld %lld %lld %lld | %lld %lld %lld %lld | %lld %lld %lld %lld %lld\n",
+                   C, K, (int)BWD, (int)FOLD, (int)WG, (int)blockIdx.x, wv * 7, r_end - r_beg,
+                   d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+        }
+    }
+#endif
 }
 
 // One or two INDEPENDENT convolutions of the same template configuration in one launch (the up- / low-branch Bottleneck
@@ -592,7 +677,11 @@ bool c1_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, C1Plan& pl)
 template <int C, int K, bool BWD, bool FOLD, bool WG, bool RES>
 int c1_launch_t(const fpd_conv_t& a, const fpd_conv_t* b, const C1Plan& pl, hipStream_t st) {
     static LdsAttr configured;
+#ifdef FPD_C1_TIMING
+    constexpr size_t lds = C1Geo<C, K, BWD, WG>::LDS + 1024;
+#else
     constexpr size_t lds = C1Geo<C, K, BWD, WG>::LDS;
+#endif
     static_assert(lds <= 160 * 1024, "conv_c1: LDS budget");
     if (int rc_ = configured.ensure(reinterpret_cast<const void*>(&c1_kernel<C, K, BWD, FOLD, WG, RES>), lds)) return rc_;
     C1Args args;

@@ -199,7 +199,7 @@ def test_c1_dgrad_close_to_conv_pp(case):
     assert torch.equal(res[0][0], res[1][0])
     for i, nm in ((1, 'sums'), (2, 'dw'), (3, 'dbias')):
         a, b = res[0][i], res[1][i]
-        assert ((a - b).abs() <= 1e-5 * a.abs().max() + 1e-9).all(), (nm, float((a - b).abs().max()), float(a.abs().max()))
+        assert ((a - b).abs() <= 5e-5 * a.abs().max() + 1e-9).all(), (nm, float((a - b).abs().max()), float(a.abs().max()))
 
 
 def test_c1_dgrad_is_bit_repeatable():
