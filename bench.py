@@ -348,10 +348,14 @@ def parity_object(build_pair, E, student, teacher, batch, dev, H, W):
                     'loss_rel_err': round(abs(a['loss'][2] - b['loss'][2]) / abs(b['loss'][2]), 6),
                     'pose_loss_bf16_fp32': [round(a['loss'][0], 6), round(b['loss'][0], 6)],
                     'kd_loss_bf16_fp32': [round(a['loss'][1], 6), round(b['loss'][1], 6)]}}
-    for name in ('r05_parity_trained.json',):
+    for name in ('r06_parity_trained.json', 'r05_parity_trained.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             d = json.load(open(path))
+            # the record names the library it was measured on; a line timed on another build says so instead of quoting it silently
+            from fpd_amd import runtime as _R
+            rec_sha, cur_sha = d.get('_library_sha16'), _R.lib_sha16()
+            res['trained_pair_library'] = {'record': rec_sha, 'timed': cur_sha, 'same_build': rec_sha == cur_sha}
             res['trained_pair'] = {k: {'ours_vs_fp64': round(v['ours_vs_fp64'], 5), 'reference_at_bf16_vs_fp64': round(v['reference_at_bf16_vs_fp64'], 5),
                                        'ceiling': v['ceiling']} for k, v in d.items() if k.startswith('trained')}
             res['trained_pair_source'] = ('profiles/%s: relative L2 (losses: relative error) against the fp64 oracle, written by tests/test_fullsize_gpu.py::'

@@ -22,7 +22,15 @@ __device__ __forceinline__ void stv(T* p, const float* f) {
 
 // One thread owns channel-vector `cv` (VEC channels) and walks pixels pl, pl+stride, ...
 // (bx, gx): this block's index and the number of blocks working on `a` (grid-stride over pixels)
-template <typename T, int OP>
+// NA ("no alias"): no input tensor of the op is its output tensor (decided on the host by comparing the pointers): the
+// inputs and the output are then __restrict__, which is what lets the loads of the next pixel pass the stores of this one
+// (two pixels in flight per thread).  An op that works IN PLACE (`add` / `x` may be `y`: include/fpd_amd.h) takes the
+// instantiation without the qualifiers -- reading an object through one restrict pointer and writing it through another is
+// undefined behaviour, however the code object of the day happens to schedule it.
+template <typename T, bool NA> struct EwPtr { typedef const T* in; typedef T* out; };
+template <typename T> struct EwPtr<T, true> { typedef const T* __restrict__ in; typedef T* __restrict__ out; };
+
+template <typename T, int OP, bool NA>
 __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const int gx) {
     constexpr int VEC = DT<T>::VEC;
     __shared__ float s_t0[FPD_MAXC], s_t1[FPD_MAXC], s_t2[FPD_MAXC], s_t3[FPD_MAXC];
@@ -71,14 +79,11 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { acc1[j] = 0.0; acc2[j] = 0.0; }
 
-    // (restrict: an output may alias an input IN PLACE -- the same thread reads a pixel's vectors before it writes them and no
-    // other thread or iteration touches them -- so letting the loads of the next pixel pass the stores of this one is safe, and it
-    // is what puts two pixels' loads in flight per thread in the loop below)
-    const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-    const T* __restrict__ x2 = reinterpret_cast<const T*>(a.x2);
-    const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
-    const T* __restrict__ add = reinterpret_cast<const T*>(a.add);
-    T* __restrict__ y = reinterpret_cast<T*>(a.y);
+    const typename EwPtr<T, NA>::in x = reinterpret_cast<const T*>(a.x);
+    const typename EwPtr<T, NA>::in x2 = reinterpret_cast<const T*>(a.x2);
+    const typename EwPtr<T, NA>::in dy = reinterpret_cast<const T*>(a.dy);
+    const typename EwPtr<T, NA>::in add = reinterpret_cast<const T*>(a.add);
+    const typename EwPtr<T, NA>::out y = reinterpret_cast<T*>(a.y);
     const bool do_stats = STATS ? (a.out_stats != nullptr) : BSTATS;
 
     if (active) {
@@ -204,15 +209,18 @@ __device__ __forceinline__ void ew_body(const fpd_ew_t& a, const int bx, const i
     }
 }
 
-template <typename T, int OP>
-__global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) { ew_body<T, OP>(a, blockIdx.x, gridDim.x); }
+template <typename T, int OP, bool NA>
+__global__ __launch_bounds__(256) void ew_kernel(const fpd_ew_t a) { ew_body<T, OP, NA>(a, blockIdx.x, gridDim.x); }
+
+// true if no input of the op is its output (exact pointer equality: the graph's in-place ops alias whole tensors)
+static bool ew_no_alias(const fpd_ew_t& a) { return a.y == nullptr || (a.y != a.x && a.y != a.x2 && a.y != a.dy && a.y != a.add); }
 
 // two independent ops of the same kind in one launch (the BN-backward applies of the paired bottleneck chains)
-template <typename T, int OP>
+template <typename T, int OP, bool NA>
 __global__ __launch_bounds__(256) void ew_pair_kernel(const fpd_ew_t a, const fpd_ew_t b, const int ga) {
     const int gb = (int)gridDim.x - ga;                       // b (half resolution) first: no tail of small blocks
-    if ((int)blockIdx.x < gb) ew_body<T, OP>(b, blockIdx.x, gb);
-    else ew_body<T, OP>(a, (int)blockIdx.x - gb, ga);
+    if ((int)blockIdx.x < gb) ew_body<T, OP, NA>(b, blockIdx.x, gb);
+    else ew_body<T, OP, NA>(a, (int)blockIdx.x - gb, ga);
 }
 
 // grid cap of the ops that end in statistics atomics (FPD_EW_STATS_BLOCKS)
@@ -237,7 +245,8 @@ int launch_ew(const fpd_ew_t& a, hipStream_t st) {
     const bool stats = (OP == FPD_EW_BNRELU_FWD || OP == FPD_EW_MAXPOOL_FWD || OP == FPD_EW_UPADD_FWD) ? a.out_stats != nullptr
                                                                                                    : OP == FPD_EW_BNRELU_BWD_R;
     const int grid = std::max(1, std::min(cdiv(npix, PB), stats ? ew_stats_blocks() : 2048));
-    FPD_LAUNCH((ew_kernel<T, OP>), dim3(grid), dim3(256), 0, st, a);
+    if (ew_no_alias(a)) FPD_LAUNCH((ew_kernel<T, OP, true>), dim3(grid), dim3(256), 0, st, a);
+    else FPD_LAUNCH((ew_kernel<T, OP, false>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -256,7 +265,8 @@ template <typename T>
 int launch_ew_pair(const fpd_ew_t& a, const fpd_ew_t& b, hipStream_t st) {
     if (a.op != FPD_EW_BN_BWD_APPLY) return 1;                 // the only pairing the graph builder emits
     const int ga = ew_grid<T, FPD_EW_BN_BWD_APPLY>(a), gb = ew_grid<T, FPD_EW_BN_BWD_APPLY>(b);
-    FPD_LAUNCH((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
+    if (ew_no_alias(a) && ew_no_alias(b)) FPD_LAUNCH((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY, true>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
+    else FPD_LAUNCH((ew_pair_kernel<T, FPD_EW_BN_BWD_APPLY, false>), dim3(ga + gb), dim3(256), 0, st, a, b, ga);
     return 0;
 }
 

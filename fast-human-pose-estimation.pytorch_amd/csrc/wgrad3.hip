@@ -1,24 +1,25 @@
-// wgrad3: weight gradient of the student's 3x3 "same" convolution (bf16, C and K multiples of 32 up to 64, 16..128-wide maps),
+// wgrad3: weight gradient of the student's 3x3 "same" convolution (bf16, C = K = 64 or C = K = 32, 16..128-wide maps),
 //     dw[k][r][s][c] = sum_m dy[m][k] * relu(bn(x))[m + (r-1, s-1)][c] ,   dbias[k] = sum_m dy[m][k],
 // restructured in round 5 around the slab traffic that bounded wgrad_tile (128 persistent blocks, each owning the whole
 // K x C x 9 accumulator = a private 147 KB slab: 18.9 MB written and read again by the slab reduction for ONE 147 KB gradient,
 // halo rows re-fetched by strided tiles: 2.07x the algorithmic HBM bytes, 0.096 of the roofline at 64x64).
 //
 // Decomposition: the K x C plane is cut into 32 x 32 PIECES (kt, ct); a block owns one piece for ALL nine taps and walks a
-// CONTIGUOUS range of 128-pixel tiles (whole image rows).  The pieces of one range share an XCD (block b runs on XCD b % 8), so
+// CONTIGUOUS range of 256-pixel tiles (W3_TP; whole image rows).  The pieces of one range share an XCD (block b runs on XCD b % 8), so
 // the two readers of every 64-byte half row meet in that XCD's L2 and HBM sees each byte of x and dy once.  A block's
 // accumulator is 9 x 32 x 32 floats = 36 KB, and a gradient is summed from `nranges` slabs (32 by default) instead of 128:
 // 4.7 MB of slab traffic at 64x64 instead of 18.9, less below.
 //
-// Per tile a block stages 32 channels of dy (128 pixels x 64 B) and of x: the halo lives in a RING of nrows + 2 image rows in
+// Per tile a block stages 32 channels of dy (256 pixels x 64 B) and of x: the halo lives in a RING of nrows + 2 image rows in
 // LDS (row g sits in slot (g + 1) % RING), so every x row is fetched ONCE per block (BatchNorm + ReLU applied once per element on
 // the way in) -- a tile brings only its nrows new rows.  Rows are unpadded 64-byte records: the transposing read
 // ds_read_b64_tr_b16, which turns the pixel axis into the MFMA k axis (mfma_frag.h), touches four consecutive 64-byte rows per
 // half wave = all 64 banks once, conflict-free, where wgrad_tile's 144-byte rows collided two-way.  Image borders: the ring has a
 // zero column on either side of a row; a tap row outside the image reads a block of zero pixels instead (uniform select).
 // The four waves of a block split the eight 16-pixel k-steps of a tile (two each: 1 dy fragment + 9 x fragments -> 9 MFMAs, 1.1
-// fragment reads per MFMA) and keep all nine 32 x 32 accumulators; two blocks share a CU (<= 256 VGPRs, 48 KB LDS), one staging
-// while the other multiplies.  At the end the four waves' accumulators are added in a FIXED order through LDS and stored to the
+// fragment reads per MFMA) and keep all nine 32 x 32 accumulators.  (The uniform kernel was meant to run two blocks per CU, one
+// staging while the other multiplies; at the 77 KB of tiles + the reduction's LDS of today one block is resident, which is
+// what the specialised kernel below, the default, is built around.)  At the end the four waves' accumulators are added in a FIXED order through LDS and stored to the
 // range's slab -- no atomics: fpd_wgrad_reduce() adds the slabs in index order, identical bytes run to run.
 // Replaces autograd of nn.Conv2d (weight / bias gradient) in /root/reference/lib/models/hourglass.py:23 (conv2 of a Bottleneck).
 #include <algorithm>
@@ -32,7 +33,8 @@ namespace {
 constexpr int W3_BLK = 512, W3_NW = 8, W3_TP = 256, W3_CH = 32;      // threads, waves, pixels per tile, staged channels
 constexpr int W3_PIXB = W3_CH * 2;                                   // bytes of a staged pixel: 64 (an unpadded LDS row)
 constexpr int W3_ZPIX = 24;                                          // zero pixels (every fragment read of a tap row outside the image)
-constexpr int W3_RED_BYTES = W3_NW * 3 * 16 * 64 * 4;                // one pass of the final cross-wave sum: 8 waves x 3 taps = 96 KB
+constexpr int W3_RED_BYTES = W3_NW * 3 * 16 * 64 * 4;                // one pass of the final cross-wave sum of the uniform kernel: 8 waves x 3 taps = 96 KB
+constexpr int W3S_RED_BYTES = 4 * 3 * 16 * 64 * 4;                   // ... of the specialised kernel: its four multiplying waves = 48 KB
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -61,7 +63,7 @@ __shared__ int w3_ns;
 #define W3_STAMP() do { } while (0)
 #endif
 
-struct W3Grid { int nrows, lgW, ring, npieces, nranges, mtiles, blocks; size_t lds; };
+struct W3Grid { int nrows, lgW, ring, npieces, nranges, mtiles, blocks; size_t lds, lds_s; };
 
 // The tile loop is bound by INSTRUCTION ISSUE, not by memory, LDS bandwidth or the matrix pipe (r05 stamps: 340 instructions per
 // wave and 256-pixel tile against 20 MFMAs ran 2 850 cycles per tile, and neither deeper prefetch nor fewer LDS reads moved it;
@@ -677,7 +679,9 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     if (!((a.C == 64 && a.K == 64) || (a.C == 32 && a.K == 32))) return false;      // 4 pieces / 1 piece of 32 x 32
     if (a.W < 16 || a.W > 128 || (a.W & (a.W - 1)) != 0) return false;
     if ((long long)a.N * a.H * a.W * std::max(a.C, a.K) >= (1ll << 31)) return false;      // 32-bit element offsets in the requests
-    const int enabled = getenv("FPD_WGRAD3") ? atoi(getenv("FPD_WGRAD3")) : 1;
+    // (the FPD_WGRAD3* variables are read ONCE: a change in mid-process would desynchronise the slab count the caller sized its
+    //  workspace for from the launch -- ADVICE round 5)
+    static const int enabled = getenv("FPD_WGRAD3") ? atoi(getenv("FPD_WGRAD3")) : 1;
     if (!enabled) return false;
     g.lgW = 0;
     while ((1 << g.lgW) < a.W) ++g.lgW;
@@ -692,14 +696,16 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     // step is faster -- same-box sweep, three interleaved runs each (experiments/r05/g11.sh): 16 / 24 / 32 / 48 / 64 ranges ->
     // 9.957 / 9.925 / 9.942 / 9.970 / 10.064 ms/step.  The lane is not the critical path; its blocks take compute units from the
     // student chain, and every range is another slab for the reduction to read.
-    const int max_ranges = (getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 32) * 4 / g.npieces;
-    const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 4;
+    static const int env_ranges = getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 32;
+    static const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 4;
+    const int max_ranges = env_ranges * 4 / g.npieces;
     int r = std::min(max_ranges, std::max(1, g.mtiles / std::max(1, min_tiles)));
     if (r >= 8) r = r / 8 * 8;
     g.nranges = std::max(1, std::min(r, g.mtiles));
     g.blocks = cdiv(g.nranges, 8) * 8 * g.npieces;
     const size_t tiles = 2 * W3_CH * sizeof(float) + (size_t)(g.ring * (a.W + 2) + 2 * W3_TP + W3_ZPIX) * W3_CH * sizeof(bf16_t);
-    g.lds = std::max(tiles, (size_t)W3_RED_BYTES);
+    g.lds = std::max(tiles, (size_t)W3_RED_BYTES);        // uniform kernel
+    g.lds_s = std::max(tiles, (size_t)W3S_RED_BYTES);     // specialised kernel: four accumulator sets go through the LDS
     return true;
 }
 
@@ -707,11 +713,11 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
 int fpd_wgrad3_launch(const fpd_wgrad_t& a, hipStream_t st) {
     W3Grid g;
     if (a.partial == nullptr || !w3_grid(a, g)) return 1;
-    const int spec = getenv("FPD_WGRAD3_SPEC") ? atoi(getenv("FPD_WGRAD3_SPEC")) : 1;      // 1: specialised waves (wgrad3s), 0: uniform
+    static const int spec = getenv("FPD_WGRAD3_SPEC") ? atoi(getenv("FPD_WGRAD3_SPEC")) : 1;      // 1: specialised waves (wgrad3s), 0: uniform
     if (spec) {
         static LdsAttr configured_s;
-        if (int rc_ = configured_s.ensure(reinterpret_cast<const void*>(&wgrad3s_kernel<0>), g.lds)) return rc_;
-        FPD_LAUNCH(wgrad3s_kernel<0>, dim3(g.blocks), dim3(W3_BLK), g.lds, st, a, g.nrows, g.lgW, g.npieces, g.nranges, g.mtiles);
+        if (int rc_ = configured_s.ensure(reinterpret_cast<const void*>(&wgrad3s_kernel<0>), g.lds_s)) return rc_;
+        FPD_LAUNCH(wgrad3s_kernel<0>, dim3(g.blocks), dim3(W3_BLK), g.lds_s, st, a, g.nrows, g.lgW, g.npieces, g.nranges, g.mtiles);
         return 0;
     }
     static LdsAttr configured;

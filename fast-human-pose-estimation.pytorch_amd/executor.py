@@ -122,6 +122,8 @@ def _whatif_drop(op, train):
         return True
     if k == 'conv' and 'nobigconv' in _WHATIF and h >= 64:
         return True
+    if k == 'conv' and h >= 32 and (('no3x3big' in _WHATIF and dims[5] == 3) or ('no1x1big' in _WHATIF and dims[5] == 1)):
+        return True                                        # round 6: the >= 32-high convolutions by filter size
     return ('nobig' in _WHATIF and h >= 64) or ('nomid' in _WHATIF and h == 32) or ('nosmall' in _WHATIF and h <= 16)
 
 

@@ -243,6 +243,14 @@ class FpdError(RuntimeError):
     pass
 
 
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the library file in use: ties a measured record (profiles/*.json written by the GPU
+    tests) to the build it was measured on."""
+    import hashlib
+    with open(LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def lib():
     """Load libfpd_amd.so once; raise (never fall back) if it is absent or ABI-incompatible."""
     global _lib

@@ -93,6 +93,10 @@ def check(label, ours, ref_bf16, floor, ceiling, slack=1.5):
         import json
         path = os.environ['FPD_WRITE_PARITY_JSON']
         d = json.load(open(path)) if os.path.exists(path) else {}
+        from fpd_amd import runtime as _R
+        if d.get('_library_sha16') not in (None, _R.lib_sha16()):
+            d = {}                                         # figures of another build: start the record over
+        d['_library_sha16'] = _R.lib_sha16()               # bench.py flags the record when it times a different library
         d[label] = {'ours_vs_fp64': float(ours), 'reference_at_bf16_vs_fp64': float(ref_bf16), 'floor': floor, 'ceiling': ceiling, 'slack': slack}
         json.dump(d, open(path, 'w'), indent=1, sort_keys=True)
     assert ours <= max(floor, slack * ref_bf16), (label, 'less accurate than %.1fx the reference at bf16' % slack, ours, ref_bf16)
@@ -329,47 +333,53 @@ def test_bf16_training_converges_like_fp32():
     """VERDICT r2 #3d: STEPS (>= 200) FPD steps on a fixed, learnable synthetic set (16 colour-coded-blob batches, cycled) from
     the same initial student, against the same frozen TRAINED teacher (committed fixture), once in the bf16 build and once in
     the fp32 parity build; then one more pass over the 16 batches with lr = 0 as the evaluation (train-mode forward: per-batch
-    BN statistics, the metric of function.py:154-155).  The bf16 run must end where the fp32 run ends: total loss within 5 %,
-    PCK@0.5 of the last student map (device metric, ~430 visible joints) within 0.04 (the realisation noise measured in round 5) -- and both must actually have learned."""
+    BN statistics, the metric of function.py:154-155).  The bf16 run must end where the fp32 run ends: total loss within 5 %
+    for every initial student, and PCK@0.5 of the last student map (device metric, ~430 visible joints per pass) within 0.02
+    ON AVERAGE OVER THREE INITIAL STUDENTS (ADVICE round 5 / VERDICT r5 weak #1a: the end point of one 600-step trajectory is
+    one realisation of a chaotic system -- a pure regrouping of fp32 sums moved the fp32 build's own figure by 0.035 -- so a
+    single-seed bound either flakes or has to be tuned to the observed value; the mean over seeds is held to the original
+    0.02, widened only by what the seeds themselves show: twice the standard error of the difference of the two means)."""
     from fpd_amd import executor as E
     from fpd_amd.lib.models import hourglass
     STEPS = 600
+    SEEDS = (1, 2, 3)
     name = 'tiny'
     c = _cases.CONFIGS[name]
     _, t_sd = trained_state_dicts()
     B, (W, H) = c['batch'], c['image']
     batches = [fpd_ref.blob_batch(9000 + i, B, c['joints'], c['image'], c['heat']) for i in range(16)]
-    s0 = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(c['s'][0], c['s'][1], c['joints']), 1)
-    out = {}
-    for dt in ('fp32', 'bf16'):
-        student = hourglass.get_pose_net(_cfg(c['s'][0], c['s'][1], c['joints'], dt), is_train=True)
-        teacher = hourglass.get_pose_net(_cfg(c['t'][0], c['t'][1], c['joints'], dt), is_train=False)
-        student.load_state_dict({k: v.clone() for k, v in s0.items()}, strict=True)
-        teacher.load_state_dict(t_sd, strict=True)
-        student, teacher = student.cuda(), teacher.cuda()
-        step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5, lr=1e-3)
-        metric = step.enable_metric()
-        for it in range(STEPS):
-            step.set_batch(*batches[it % 16])
-            step.step()
-        first = metric.drain(full=True)
-        step.set_lr(0.0)
-        for it in range(16):
-            step.set_batch(*batches[it])
-            step.step()
-        ev = metric.drain(full=True)
-        assert len(first) == STEPS and len(ev) == 16
-        tot0 = np.mean([0.5 * e[2] + 0.5 * e[3] for e in first[:16]])
-        tot = np.mean([0.5 * e[2] + 0.5 * e[3] for e in ev])
-        acc = np.mean([e[0] for e in ev])
-        out[dt] = (tot0, tot, acc)
-        print('%s: total loss %.5f (first 16 steps) -> %.5f, PCK@0.5 %.3f after %d steps' % (dt, tot0, tot, acc, STEPS))
-        del step, student, teacher
-        torch.cuda.empty_cache()
-    (f0, l32, a32), (_, l16, a16) = out['fp32'], out['bf16']
-    assert l32 < 0.25 * f0 and a32 > 0.5, 'the fp32 run did not learn'
-    assert abs(l16 - l32) <= 0.05 * l32, ('final loss', l16, l32)
-    # PCK after 600 steps is one realisation of a chaotic trajectory for EITHER build: a pure regrouping of the fp32 weight-gradient
-    # sums on the small maps (round 5: four tiles per block instead of one) moved the fp32 build's own figure 0.639 -> 0.674 and the
-    # bf16 build's 0.640 -> 0.651 with every oracle comparison unchanged -- the bound is that realisation noise, not 0.02
-    assert abs(a16 - a32) <= 0.04, ('final PCK', a16, a32)
+    out = {'fp32': [], 'bf16': []}
+    for seed in SEEDS:
+        s0 = fpd_ref.synth_state_dict(hourglass_ref.hourglass_keys(c['s'][0], c['s'][1], c['joints']), seed)
+        for dt in ('fp32', 'bf16'):
+            student = hourglass.get_pose_net(_cfg(c['s'][0], c['s'][1], c['joints'], dt), is_train=True)
+            teacher = hourglass.get_pose_net(_cfg(c['t'][0], c['t'][1], c['joints'], dt), is_train=False)
+            student.load_state_dict({k: v.clone() for k, v in s0.items()}, strict=True)
+            teacher.load_state_dict(t_sd, strict=True)
+            student, teacher = student.cuda(), teacher.cuda()
+            step = E.FusedFPDStep(student.device_state(), student.cfg_hg, teacher.device_state(), teacher.cfg_hg, B, H, W, alpha=0.5, lr=1e-3)
+            metric = step.enable_metric()
+            for it in range(STEPS):
+                step.set_batch(*batches[it % 16])
+                step.step()
+            first = metric.drain(full=True)
+            step.set_lr(0.0)
+            for it in range(16):
+                step.set_batch(*batches[it])
+                step.step()
+            ev = metric.drain(full=True)
+            assert len(first) == STEPS and len(ev) == 16
+            tot0 = np.mean([0.5 * e[2] + 0.5 * e[3] for e in first[:16]])
+            tot = np.mean([0.5 * e[2] + 0.5 * e[3] for e in ev])
+            acc = np.mean([e[0] for e in ev])
+            out[dt].append((tot0, tot, acc))
+            print('seed %d %s: total loss %.5f (first 16 steps) -> %.5f, PCK@0.5 %.3f after %d steps' % (seed, dt, tot0, tot, acc, STEPS))
+            del step, student, teacher
+            torch.cuda.empty_cache()
+    for (f0, l32, a32), (_, l16, a16) in zip(out['fp32'], out['bf16']):
+        assert l32 < 0.25 * f0 and a32 > 0.5, 'the fp32 run did not learn'
+        assert abs(l16 - l32) <= 0.05 * l32, ('final loss', l16, l32)
+    p32, p16 = np.array([o[2] for o in out['fp32']]), np.array([o[2] for o in out['bf16']])
+    se = float(np.sqrt((p32.var(ddof=1) + p16.var(ddof=1)) / len(SEEDS)))      # standard error of the difference of the two means
+    print('PCK@0.5 over %d initial students: fp32 %.4f, bf16 %.4f, standard error of the difference %.4f' % (len(SEEDS), p32.mean(), p16.mean(), se))
+    assert abs(p16.mean() - p32.mean()) <= max(0.02, 2.0 * se), ('final PCK (mean over seeds)', p16.mean(), p32.mean(), se)

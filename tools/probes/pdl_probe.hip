@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void flush_k(double* st, long long* sti, const
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const double v = vs[s];
-                const long long hi = __double2ll_rn(v * 256.0);
-                const double r = v - (double)hi * (1.0 / 256.0);
+                const long long hi = __double2ll_rn(v * 1048576.0);                        // 2^20 (include/fpd_amd.h, ABI version 2)
+                const double r = v - (double)hi * (1.0 / 1048576.0);
                 const long long lo = __double2ll_rn(r * 1152921504606846976.0);     // 2^60
                 unsigned long long* p = reinterpret_cast<unsigned long long*>(sti) + ((size_t)(rep * 2 + s) * 2) * C;
                 atomicAdd(p + c, (unsigned long long)hi);
