@@ -13,6 +13,10 @@ int fpd_conv_mfma_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_tile_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_pp_launch(const fpd_conv_t& a, hipStream_t st);
 int fpd_conv_c1_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_c3_launch(const fpd_conv_t& a, hipStream_t st);
+int fpd_conv_c3_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
+int fpd_conv_c3_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b);
+int fpd_conv_c3_option(int which, int value);
 int fpd_conv_c1_pair_launch(const fpd_conv_t& a, const fpd_conv_t& b, hipStream_t st);
 int fpd_conv_c1_fold_ok(const fpd_conv_t& a, const fpd_conv_t* b);
 int fpd_conv_c1_option(int which, int value);
@@ -134,6 +138,9 @@ int fpd_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "conv_c1")) return fpd_conv_c1_option(0, value);
     if (!strcmp(name, "conv_c1_blocks")) return fpd_conv_c1_option(1, value);
     if (!strcmp(name, "conv_c1_launches")) return fpd_conv_c1_option(2, value);      // (read-only: launches served so far)
+    if (!strcmp(name, "conv_c3")) return fpd_conv_c3_option(0, value);
+    if (!strcmp(name, "conv_c3_blocks")) return fpd_conv_c3_option(1, value);
+    if (!strcmp(name, "conv_c3_launches")) return fpd_conv_c3_option(2, value);
     if (!strcmp(name, "wgrad_tile_only")) { g_wgrad_tile_only = value; return 0; }
     return fpd_fail(-2, "set_option: unknown option '%s'", name);
 }
@@ -163,6 +170,7 @@ static int validate_conv(const fpd_conv_t* a) {
 static int dispatch_conv(const fpd_conv_t* a, hipStream_t st) {
     int rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c1_launch(*a, st);      // big maps, 1x1: streaming kernel
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c3_launch(*a, st);      // big maps, 3x3 64 -> 64: strip kernel
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_launch(*a, st);      // big maps: persistent kernel
     FPD_REQUIRE(rc != 1 || a->wg_partial == nullptr, "conv: a fused weight gradient (wg_partial) needs the persistent kernel; "
                 "fpd_conv_fused_wgrad_partials() reports 0 for this launch");
@@ -184,12 +192,13 @@ int fpd_conv_forward(const fpd_conv_t* a, fpd_stream_t stream) {
 
 int fpd_conv_fold_supported(const fpd_conv_t* a) {
     if (!a || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(a) != 0) return 0;
-    return (fpd_conv_c1_fold_ok(*a, nullptr) || fpd_conv_pp_fold_ok(*a, nullptr) || fpd_conv_tile_fold_ok(*a)) ? 1 : 0;
+    return (fpd_conv_c1_fold_ok(*a, nullptr) || fpd_conv_c3_fold_ok(*a, nullptr) || fpd_conv_pp_fold_ok(*a, nullptr) || fpd_conv_tile_fold_ok(*a)) ? 1 : 0;
 }
 int fpd_conv_pair_fold_supported(const fpd_conv_pair_t* p) {
     if (!p || g_fpd_backend != FPD_BACKEND_MFMA || validate_conv(&p->a) != 0 || validate_conv(&p->b) != 0) return 0;
     // the dispatch order of fpd_conv_forward_pair(): streaming pair, persistent pair, halo-tile pair, two single launches
     if (fpd_conv_c1_fold_ok(p->a, &p->b)) return 1;
+    if (fpd_conv_c3_fold_ok(p->a, &p->b)) return 1;
     if (fpd_conv_pp_fold_ok(p->a, &p->b)) return 1;
     const int r = fpd_conv_tile_pair_fold_ok(p->a, p->b);
     if (r >= 0) return r;
@@ -240,6 +249,7 @@ int fpd_conv_forward_pair(const fpd_conv_pair_t* p, fpd_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = 1;
     if (g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c1_pair_launch(p->a, p->b, st);
+    if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_c3_pair_launch(p->a, p->b, st);
     if (rc == 1 && g_fpd_backend == FPD_BACKEND_MFMA) rc = fpd_conv_pp_pair_launch(p->a, p->b, st);
     FPD_REQUIRE(rc != 1 || (p->a.wg_partial == nullptr && p->b.wg_partial == nullptr),
                 "conv_pair: fused weight gradients need the persistent kernel; fpd_conv_pair_fused_wgrad_partials() reports 0 for this launch");

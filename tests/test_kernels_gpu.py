@@ -68,13 +68,25 @@ class Bench:
             # the persistent ping-pong convolution (csrc/conv_pp.hip) forced for every in-domain bf16 shape; ('pp', n): n blocks,
             # so that a block owns many tiles (uneven ranges, ragged last tiles, long ping-pong loops) even on small tensors
             blocks = backend[1] if isinstance(backend, tuple) else 256
-            pm, pb, cm = R.set_option('conv_pp', 2), R.set_option('conv_pp_blocks', blocks), R.set_option('conv_c1', 0)
+            pm, pb, cm, c3m = R.set_option('conv_pp', 2), R.set_option('conv_pp_blocks', blocks), R.set_option('conv_c1', 0), R.set_option('conv_c3', 0)
             try:
                 return self.run(ops, 0, partials)
             finally:
                 R.set_option('conv_pp', pm)
                 R.set_option('conv_pp_blocks', pb)
                 R.set_option('conv_c1', cm)
+                R.set_option('conv_c3', c3m)
+        if backend == 'c3' or (isinstance(backend, tuple) and backend[0] == 'c3'):
+            # the strip kernel for the 3x3 64 -> 64 convolutions (csrc/conv_c3.hip) forced for every in-domain shape; ('c3', n): n blocks
+            blocks = backend[1] if isinstance(backend, tuple) else 256
+            cm, cb = R.set_option('conv_c3', 2), R.set_option('conv_c3_blocks', blocks)
+            n0 = R.set_option('conv_c3_launches', 0)
+            try:
+                return self.run(ops, 0, partials)
+            finally:
+                self.n_c3 = R.set_option('conv_c3_launches', 0) - n0
+                R.set_option('conv_c3', cm)
+                R.set_option('conv_c3_blocks', cb)
         if backend == 'c1' or (isinstance(backend, tuple) and backend[0] == 'c1'):
             # the streaming 1x1 convolution (csrc/conv_c1.hip) forced for every in-domain shape; ('c1', n): n blocks, so that a
             # block owns several rounds (uneven ranges, a ragged last round) even on small tensors.  self.n_c1 = launches it served
