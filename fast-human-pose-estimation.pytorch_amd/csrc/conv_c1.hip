@@ -600,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void c1_kernel(const C1Args p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FPD_C1: 0 = never, 1 = launches of >= FPD_C1_MIN_PX pixels (default), 2 = whenever the shape is in the domain (tests:
-// fpd_set_option("conv_c1", v)); FPD_C1_BLOCKS: persistent blocks of a launch (default 256 = one per CU).
+// fpd_set_option("conv_c1", v)); FPD_C1_BLOCKS: persistent blocks of a launch (default 192 of the 256 CUs, see c1_blocks()).
 int g_c1_mode = -1, g_c1_blocks = -1;
 std::atomic<int> g_c1_launches{0};                       // launches this kernel has served (tests: "conv_c1_launches")
 int c1_mode() {
@@ -608,7 +608,10 @@ int c1_mode() {
     return g_c1_mode;
 }
 int c1_blocks() {
-    if (g_c1_blocks < 0) { const char* e = getenv("FPD_C1_BLOCKS"); g_c1_blocks = e ? atoi(e) : 256; }
+    // (192, not 256: a resident block owns most of its CU's LDS, and the frozen teacher's fused Bottlenecks -- 128 blocks of 151 KB on
+    //  another stream -- need compute units of their own; r06 sweep inside the step, one box: 160 / 192 / 224 / 256 blocks ->
+    //  9.21 / 9.15 / 9.17-9.45 / 9.25 ms)
+    if (g_c1_blocks < 0) { const char* e = getenv("FPD_C1_BLOCKS"); g_c1_blocks = e ? atoi(e) : 192; }
     return g_c1_blocks < 1 ? 1 : g_c1_blocks;
 }
 int c1_min_px() {

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void c3_kernel(const C3Args p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FPD_C3: 0 = never, 1 = launches of >= FPD_C3_MIN_PX pixels (default), 2 = whenever the shape is in the domain (tests:
-// fpd_set_option("conv_c3", v)); FPD_C3_BLOCKS: persistent blocks of a launch (default 256 = one per CU).
+// fpd_set_option("conv_c3", v)); FPD_C3_BLOCKS: persistent blocks of a launch (default 160 of the 256 CUs, see c3_blocks()).
 int g_c3_mode = -1, g_c3_blocks = -1;
 std::atomic<int> g_c3_launches{0};
 int c3_mode() {
@@ -449,7 +449,9 @@ int c3_mode() {
     return g_c3_mode;
 }
 int c3_blocks() {
-    if (g_c3_blocks < 0) { const char* e = getenv("FPD_C3_BLOCKS"); g_c3_blocks = e ? atoi(e) : 256; }
+    // (160, not 256: the block owns its CU's LDS (157 KB) and the frozen teacher's fused Bottlenecks on the other stream need compute
+    //  units of their own; r06 sweep inside the step, one box: 128 / 160 / 192 / 224 / 256 blocks -> 9.02 / 9.07 / 9.08 / 9.21 / 9.25 ms)
+    if (g_c3_blocks < 0) { const char* e = getenv("FPD_C3_BLOCKS"); g_c3_blocks = e ? atoi(e) : 160; }
     return g_c3_blocks < 1 ? 1 : g_c3_blocks;
 }
 int c3_min_px() {
