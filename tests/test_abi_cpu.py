@@ -138,15 +138,28 @@ def test_host_side_dispatch_predicates_of_round_3_without_a_device(runtime):
     assert fold(_conv(R, 32, 32, 32, 64, 128, 1)) == 1
     assert fold(_conv(R, 32, 16, 16, 64, 128, 1)) == 1          # 64 tiles: halo-tile kernel, TN drops to 2
     assert fold(_conv(R, 32, 4, 4, 64, 64, 3)) == 1
-    # 128 tiles x 128 output channels: the halo-tile kernel keeps TN = 4, for which no FOLD variant is compiled
+    # 128 tiles x 128 output channels: the halo-tile kernel keeps TN = 4, for which no FOLD variant is compiled -- since round 6
+    # the streaming 1x1 kernel (conv_c1, from 2048 pixels) serves this launch, so the fold is available; without it: not
+    assert fold(_conv(R, 4, 64, 64, 64, 128, 1)) == 1
+    prev_c1 = lib.fpd_set_option(b'conv_c1', 0)
     assert fold(_conv(R, 4, 64, 64, 64, 128, 1)) == 0
+    lib.fpd_set_option(b'conv_c1', prev_c1)
+    assert fold(_conv(R, 2, 16, 16, 64, 128, 1)) == 1          # 512 pixels: below conv_c1's threshold, 4 tiles of the halo-tile kernel
     assert fold(_conv(R, 32, 64, 64, 64, 64, 3, bwd=False)) == 0        # not a BNRELU_BWD data gradient
     assert fold(_conv(R, 32, 64, 64, 64, 64, 3, bn=True)) == 0          # a prologue BN of its own
     pair = R.ConvPairT()
     pair.a, pair.b = _conv(R, 32, 64, 64, 64, 128, 1), _conv(R, 32, 32, 32, 64, 128, 1)
     assert lib.fpd_conv_pair_fold_supported(ctypes.byref(pair)) == 1
-    pair.a, pair.b = _conv(R, 4, 64, 64, 64, 128, 1), _conv(R, 4, 32, 32, 64, 128, 1)      # 160 tiles: halo-tile pair at TN = 4
+    pair.a, pair.b = _conv(R, 4, 64, 64, 64, 128, 1), _conv(R, 4, 32, 32, 64, 128, 1)      # 160 tiles: halo-tile pair at TN = 4 ...
+    assert lib.fpd_conv_pair_fold_supported(ctypes.byref(pair)) == 1                     # ... taken by conv_c1 since round 6
+    prev_c1 = lib.fpd_set_option(b'conv_c1', 0)
     assert lib.fpd_conv_pair_fold_supported(ctypes.byref(pair)) == 0
+    lib.fpd_set_option(b'conv_c1', prev_c1)
+    # the new kernels' own predicates: the 3x3 strip kernel takes 64 -> 64 on 16..64-wide maps from 32768 pixels; options round-trip
+    prev_c3 = lib.fpd_set_option(b'conv_c3', 2)
+    assert fold(_conv(R, 2, 16, 16, 64, 64, 3)) == 1 and fold(_conv(R, 2, 16, 16, 32, 32, 3)) == 1      # (32 -> 32: conv_tile's FOLD variant)
+    assert lib.fpd_set_option(b'conv_c3', prev_c3) == 2
+    assert lib.fpd_set_option(b'conv_c1_launches', 0) == 0 and lib.fpd_set_option(b'conv_c3_launches', 0) == 0
     # deterministic weight gradients: slab counts follow the dispatch order tile -> mfma -> small-C -> direct
     w = R.WgradT()
     w.x = w.dy = w.dw = 64
