@@ -668,7 +668,10 @@ struct C1Plan { int na, nb, grid; bool wg; };
 bool c1_plan(const fpd_conv_t& a, const fpd_conv_t* b, bool want_wg, C1Plan& pl) {
     const int ra = c1_rounds(a), rb = b ? c1_rounds(*b) : 0;
     pl.wg = want_wg && c1_wg_shape(a) && (b == nullptr || c1_wg_shape(*b));
+    // blocks under the cap, balanced: every block runs the same number of rounds (512 rounds under a cap of 192 -> 171 blocks of 3,
+    // not 192 blocks of which two thirds run 3 and the rest 2)
     int total = std::max(1, std::min(c1_blocks(), ra + rb));
+    total = cdiv(ra + rb, cdiv(ra + rb, total));
     pl.nb = 0;
     if (b != nullptr) {
         if (total < 2) return false;

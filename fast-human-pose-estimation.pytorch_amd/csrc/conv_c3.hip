@@ -504,7 +504,9 @@ bool c3_plan(const fpd_conv_t& a, const fpd_conv_t* b, C3Plan& pl) {
     pl.gb = b ? c3_geo(*b) : pl.ga;
     pl.gb.nblk = 0;
     const int sa = pl.ga.nstrip, sb = b ? pl.gb.nstrip : 0;
-    const int total = std::max(1, std::min(c3_blocks(), sa + sb));
+    // blocks under the cap, balanced: every block walks the same number of strips (conv_c1.hip)
+    int total = std::max(1, std::min(c3_blocks(), sa + sb));
+    total = cdiv(sa + sb, cdiv(sa + sb, total));
     if (b != nullptr) {
         if (total < 2) return false;
         pl.gb.nblk = std::max(1, std::min(total - 1, (int)((long long)total * sb / (sa + sb))));
