@@ -226,10 +226,10 @@ def conv_classes(step, R, peak_tflops, launches=12, top=6):
 
 def pmc_traffic_of_class(shape_tag, sub):
     """HBM bytes per launch of a convolution class from the committed rocprofv3 --pmc passes of this round, keyed on the shape
-    tag of the library's launch log (profiles/r05_<sub>hbm_traffic.csv, else round 4's, written by tools/profile_summarize.py); (None, why)
+    tag of the library's launch log (profiles/r06_<sub>hbm_traffic.csv, else an earlier round's, written by tools/profile_summarize.py); (None, why)
     if that table or row is absent."""
     import csv
-    for pfx in ('r05', 'r04', 'r04a'):
+    for pfx in ('r06', 'r05', 'r04', 'r04a'):
         path = os.path.join(ROOT, 'profiles', '%s_%shbm_traffic.csv' % (pfx, sub))
         if not os.path.exists(path):
             continue
@@ -567,7 +567,7 @@ def main():
         # HBM bytes/launch from separate rocprofv3 --pmc passes (tools/pmc_bneck.sh), only if that file was measured at the
         # launch geometry timed here (grid cap): a file from another geometry is refused, not quoted
         traffic, traffic_note = None, 'no PMC file under profiles/'
-        for name in ('r05_pmc_bneck64.json', 'r04_pmc_bneck64.json', 'r04a_pmc_bneck64.json', 'r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
+        for name in ('r06_pmc_bneck64.json', 'r05_pmc_bneck64.json', 'r04_pmc_bneck64.json', 'r04a_pmc_bneck64.json', 'r03_pmc_bneck64.json', 'r02_pmc_bneck64.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(pmc):
                 d = json.load(open(pmc))

@@ -678,26 +678,9 @@ static int run_op(const fpd_op& o, fpd_stream_t s) {
     return fpd_fail(-2, "run_op: unknown op %d", o.type);
 }
 
-static int lane_priority() {            // FPD_LANE_PRIORITY=low|high|normal(default): priority of the side-lane streams
-    static int prio = -1000;
-    if (prio == -1000) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // lo = least urgent (numerically greatest)
-        const char* e = getenv("FPD_LANE_PRIORITY");
-        prio = (e && e[0] == 'l') ? lo : (e && e[0] == 'h') ? hi : 0;
-    }
-    return prio;
-}
+static int lane_priority() { return 0; }      // side-lane streams at the default priority (stream priorities measured as a no-op eagerly, rounds 1-2; knob removed in round 6)
 
-static int side_streams() {              // FPD_SIDE_STREAMS=n: lanes 1.. share n physical streams (default: one stream per lane)
-    static int n = -1;
-    if (n < 0) {
-        const char* e = getenv("FPD_SIDE_STREAMS");
-        n = e ? atoi(e) : FPD_MAX_LANES;
-        if (n < 1) n = 1;
-    }
-    return n;
-}
+static int side_streams() { return FPD_MAX_LANES; }      // one physical stream per lane (the FPD_SIDE_STREAMS knob of rounds 1-5 never beat it)
 
 int fpd_plan_run(fpd_plan* p, int32_t begin, int32_t end, fpd_stream_t stream) {
     FPD_REQUIRE(p && begin >= 0 && end <= (int)p->ops.size() && begin <= end, "plan_run: bad range [%d,%d)", begin, end);

@@ -736,21 +736,9 @@ static int pp_min_tiles() {  // FPD_CONV_PP_MIN_TILES: smallest launch (pixel ti
     if (v < 0) { const char* e = getenv("FPD_CONV_PP_MIN_TILES"); v = e ? atoi(e) : 256; }
     return v;
 }
-static int pp_occ_cap() {    // FPD_CONV_PP_OCC: resident blocks per CU the grid is sized for (1 or 2)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_PP_OCC"); v = e ? atoi(e) : 2; }
-    return v < 1 ? 1 : v;
-}
-static int pp_blocks_bwd() { // FPD_CONV_PP_BLOCKS_BWD: persistent blocks of the data-gradient kernels (one per CU; default = FPD_CONV_PP_BLOCKS)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_PP_BLOCKS_BWD"); v = e ? atoi(e) : 0; }
-    return v > 0 ? v : pp_blocks();
-}
-static int pp_fuse_wgrad() { // FPD_CONV_PP_WGRAD: 0 = never fuse the weight gradient into the data-gradient launch
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD"); v = e ? atoi(e) : 1; }
-    return v;
-}
+static int pp_occ_cap() { return 2; }        // resident blocks per CU the forward grids are sized for (FPD_CONV_PP_OCC of rounds 3-5)
+static int pp_blocks_bwd() { return pp_blocks(); }      // data-gradient kernels: one block per CU, same count (128 / 192 / 256 / 384 -> 10.33 / 10.22 / 10.08 / 10.42 ms, round 4)
+static int pp_fuse_wgrad() { return 1; }      // 1x1 data gradients also form their weight gradient
 
 static int pp_tile_px(const fpd_conv_t& a) { return a.K > 32 ? 128 : 256; }
 static int pp_nrows(const fpd_conv_t& a) { return std::max(1, pp_tile_px(a) / a.W); }
@@ -766,16 +754,8 @@ static bool pp_domain(const fpd_conv_t& a) {
 }
 static int pp_tiles(const fpd_conv_t& a) { return cdiv(a.N * a.H, pp_nrows(a)); }
 // shapes whose data-gradient launch can carry the forward convolution's weight gradient (conv_pp_body<.., WG = true>)
-static int pp_wg_kmax() {   // FPD_CONV_PP_WGRAD_KMAX: widest data gradient (output channels) that also forms the weight gradient
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD_KMAX"); v = e ? atoi(e) : 128; }
-    return v;
-}
-static int pp_wg_ckmax() {  // FPD_CONV_PP_WGRAD_CKMAX: largest weight matrix (C x K elements) formed inside a data-gradient launch
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_PP_WGRAD_CKMAX"); v = e ? atoi(e) : 128 * 128; }
-    return v;
-}
+static int pp_wg_kmax() { return 128; }       // widest data gradient (output channels) that also forms the weight gradient
+static int pp_wg_ckmax() { return 128 * 128; }      // largest weight matrix (C x K elements) formed inside a data-gradient launch
 static bool pp_wg_shape(const fpd_conv_t& a) {
     return pp_fuse_wgrad() != 0 && pp_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && a.R == 1 && a.C >= 32 && a.K <= pp_wg_kmax() && a.C * a.K <= pp_wg_ckmax() &&
            (pp_nrows(a) * a.W) % 16 == 0;

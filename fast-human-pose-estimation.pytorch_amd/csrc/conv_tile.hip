@@ -413,12 +413,8 @@ __global__ __launch_bounds__(256, (tile_waves<TN, ALLW, FOLD>())) void conv_tile
     else conv_tile_body<T, TN, BK, ALLW, FOLD>(a, logWa, (int)blockIdx.x - nbx_b, blockIdx.y);
 }
 
-// FPD_CONV_ALLW: largest grid (blocks) that uses the all-taps-staged variant; 0 disables it
-static int allw_max_blocks() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_CONV_ALLW"); v = e ? atoi(e) : 320; }
-    return v;
-}
+// largest grid (blocks) that uses the all-taps-staged variant (the FPD_CONV_ALLW knob of rounds 4-5: 320 measured best)
+static int allw_max_blocks() { return 320; }
 template <typename T, int BK>
 static bool allw_ok(const fpd_conv_t& a, int blocks) {
     return a.R == 3 && a.C == BK && blocks <= allw_max_blocks();

@@ -457,8 +457,7 @@ __global__ __launch_bounds__(256) void stem_s2d_wgrad_kernel(const fpd_stem_t a,
 
 // return 1 = not applicable (the caller falls through to stem_fwd_mfma / the direct kernels)
 int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st) {
-    static const int enabled = getenv("FPD_STEM_S2D") ? atoi(getenv("FPD_STEM_S2D")) : 1;
-    if (!enabled || a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 64) return 1;
+    if (a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 64) return 1;
     if (a.Q > 128 || a.Q < 16 || (a.Q & (a.Q - 1)) != 0 || a.H != 2 * a.P || a.W != 2 * a.Q) return 1;
     int logQ = 0;
     while ((1 << logQ) < a.Q) ++logQ;
@@ -469,7 +468,7 @@ int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st) {
     const size_t lds = std::max((size_t)ring * (a.Q + 3) * S2_PIXB + (size_t)32 * TN * S2_WROW,
                                 (size_t)4 * 32 * TN * 2 * (33 * sizeof(float) + sizeof(double)));      // tiles | block-end statistics transposition
     const int tiles = a.N * a.P * a.Q / 128;
-    static const int cap = getenv("FPD_STEM_BLOCKS") ? atoi(getenv("FPD_STEM_BLOCKS")) : 0;
+    static const int cap = 0;        // (0 = the per-K defaults below; the FPD_STEM_BLOCKS knob of round 5 is gone)
     // K = 32: two blocks per CU (35.6 us at 512 blocks, 47.6 at 256, 44.1 at 1024); K = 64: 62.2 us at 256, 71.8 at 512 (r05, one box)
     const int blocks = std::max(1, std::min(tiles, cap > 0 ? cap : (TN == 1 ? 512 : 256)));
     static LdsAttr cfg1, cfg2;
@@ -484,14 +483,13 @@ int fpd_stem_forward_s2d_launch(const fpd_stem_t& a, hipStream_t st) {
 }
 
 static bool s2d_wgrad_ok(const fpd_stem_t& a, int& logQ, int& blocks) {
-    static const int enabled = getenv("FPD_STEM_S2D") ? atoi(getenv("FPD_STEM_S2D")) : 1;
-    if (!enabled || a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 32) return false;
+    if (a.dtype != FPD_BF16 || a.K % 8 != 0 || a.K > 32) return false;
     if (a.Q > 128 || a.Q < 16 || (a.Q & (a.Q - 1)) != 0 || a.H != 2 * a.P || a.W != 2 * a.Q) return false;
     logQ = 0;
     while ((1 << logQ) < a.Q) ++logQ;
     if (a.P % (128 >> logQ) != 0) return false;
     const int tiles = a.N * a.P * a.Q / 128;
-    static const int cap = getenv("FPD_STEM_WGRAD_BLOCKS") ? atoi(getenv("FPD_STEM_WGRAD_BLOCKS")) : 256;
+    static const int cap = 256;      // (= its slab count: 41.6 us; 128 / 512 blocks 67.4 / 52.5 us, round 5)
     blocks = std::max(1, std::min(tiles, cap));
     return true;
 }

@@ -697,7 +697,7 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
     // 9.957 / 9.925 / 9.942 / 9.970 / 10.064 ms/step.  The lane is not the critical path; its blocks take compute units from the
     // student chain, and every range is another slab for the reduction to read.
     static const int env_ranges = getenv("FPD_WGRAD3_RANGES") ? atoi(getenv("FPD_WGRAD3_RANGES")) : 32;
-    static const int min_tiles = getenv("FPD_WGRAD3_MIN_TILES") ? atoi(getenv("FPD_WGRAD3_MIN_TILES")) : 4;
+    static const int min_tiles = 4;      // fewest 256-pixel tiles per block
     const int max_ranges = env_ranges * 4 / g.npieces;
     int r = std::min(max_ranges, std::max(1, g.mtiles / std::max(1, min_tiles)));
     if (r >= 8) r = r / 8 * 8;
@@ -713,7 +713,7 @@ static bool w3_grid(const fpd_wgrad_t& a, W3Grid& g) {
 int fpd_wgrad3_launch(const fpd_wgrad_t& a, hipStream_t st) {
     W3Grid g;
     if (a.partial == nullptr || !w3_grid(a, g)) return 1;
-    static const int spec = getenv("FPD_WGRAD3_SPEC") ? atoi(getenv("FPD_WGRAD3_SPEC")) : 1;      // 1: specialised waves (wgrad3s), 0: uniform
+    static const int spec = 1;      // specialised waves (wgrad3s); the uniform kernel stays for fpd_set_option-free A/B builds (-DW3_UNIFORM would select it)
     if (spec) {
         static LdsAttr configured_s;
         if (int rc_ = configured_s.ensure(reinterpret_cast<const void*>(&wgrad3s_kernel<0>), g.lds_s)) return rc_;

@@ -384,8 +384,7 @@ bool wt_grid(const fpd_wgrad_t& a, WtGrid& g) {
     // the per-tile staging of its 128 blocks -- the hourglass' 3x3 32->32 at 128x128 is one of the last launches of the backward
     // (158 us, exposed in front of Adam): four times the blocks
     if (a.R == 3 && a.dtype == FPD_BF16 && a.C <= 32 && a.K <= 32) target = std::max(128, std::min(512, g.mtiles / 4));      // (>= 4 tiles per block: HRNet's 64x48 maps keep 192)
-    if (const char* e = getenv("FPD_WGRAD_BLOCKS")) target = atoi(e);
-    if (const char* e = getenv(a.R == 1 ? "FPD_WGRAD_BLOCKS_1" : "FPD_WGRAD_BLOCKS_3")) target = atoi(e);   // per filter size
+    // (the FPD_WGRAD_BLOCKS / _1 / _3 knobs of rounds 2-5 are gone: 256 blocks for 1x1, 128 for 3x3 measured best)
     g.gx = std::max(1, std::min(g.mtiles, cdiv(target, g.gy)));
     // 1x1 on the small maps: a block per 128-pixel tile meant 128 slabs of 32 KB for an 8 192-pixel problem (34 MB per gradient
     // class and step, r05 slab inventory) at the launch-latency floor either way: at least four tiles per block

@@ -499,7 +499,6 @@ class GraphInstance:
                                       num_blocks=cfg.get('num_blocks', 1), wlp_is_master=(self.dtype == R.F32),
                                       fuse_bneck=(self.dtype == R.BF16 and not train and env('FPD_FUSE_BNECK', '1') != '0'),
                                       pair_branches=env('FPD_PAIR', '1') != '0', fuse_head=env('FPD_FUSE_HEAD', '1') != '0',
-                                      lane_levels=int(env('FPD_LANE_LEVELS')) if env('FPD_LANE_LEVELS') else None,
                                       wgrad_batch=int(env('FPD_WGRAD_BATCH')) if env('FPD_WGRAD_BATCH') else None)
         self.A = Arenas(state.device, self.dtype, parent=state.A)
         self.low = Lowering(self.A, self.dtype)
@@ -530,10 +529,10 @@ class GraphInstance:
         self.lanes_enabled = os.environ.get('FPD_LANES', '1') != '0'
         self.schedules = {}
         # several lanes in flight: do not hand a released block to the very next tensor (false WAR dependencies)
-        # (a frozen graph has a single lane: immediate reuse keeps its working set small -- FPD_REUSE_DELAY_EVAL to experiment)
+        # (a frozen graph has a single lane: immediate reuse keeps its working set small)
         delay = int(os.environ.get('FPD_REUSE_DELAY', '400')) if self.lanes_enabled else 0
         if not self.train:
-            delay = int(os.environ.get('FPD_REUSE_DELAY_EVAL', '0'))
+            delay = 0
         act = G.plan_memory(ops, reuse_delay=delay)
         self.act_elems = act
         self.A.alloc('act', act)
@@ -668,11 +667,11 @@ class FusedFPDStep:
         if teacher_state is not None:
             assert teacher_state.dtype == self.dtype
             # The frozen teacher normalises with running statistics, so its samples are independent: the batch CAN be cut
-            # into chunks that run as separate op chains on separate streams (teacher_chunks / FPD_TEACHER_CHUNKS).
+            # into chunks that run as separate op chains on separate streams (constructor argument teacher_chunks).
             # Measured on MI355X (r01): 1 chunk 15.0 ms/step, 2 chunks 15.0, 4 chunks 17.7 -- beyond three concurrent
             # streams (teacher, student chain, weight-gradient lane) the step gets slower, so the default is 1.
             if teacher_chunks is None:
-                teacher_chunks = int(os.environ.get('FPD_TEACHER_CHUNKS', '1'))
+                teacher_chunks = 1
             while batch % teacher_chunks:
                 teacher_chunks -= 1
             cb = batch // teacher_chunks
@@ -690,7 +689,7 @@ class FusedFPDStep:
             self.ev_chunk = [torch.cuda.Event() for _ in range(teacher_chunks)]
         self._k_t = self._k_s = 0
         # 'loss' (default): the student step waits for the teacher's map in front of the fused loss; 'start': before its forward
-        self._late_teacher_wait = os.environ.get('FPD_TEACHER_WAIT', 'loss') == 'loss'
+        self._late_teacher_wait = True         # (round 3: 10.62 -> 10.51 ms; the FPD_TEACHER_WAIT=start spelling of the old order is gone)
         self.student = GraphInstance(student_state, student_cfg, batch, height, width, train=True)
         g = self.student.g
         self.hh, self.hw = g.outputs[0].shape[1:3]

@@ -25,14 +25,13 @@ STATS_REPLICAS = int(os.environ.get('FPD_STATS_REPLICAS', '4'))   # include/fpd_
 WGRAD_LANES = 1
 LANE_LEVELS = 0
 FOLD_APPLY = os.environ.get('FPD_FOLD_APPLY', '1') != '0'     # BN-backward applies evaluated by the consuming data gradient where the library offers it
-WREDUCE_PER_BATCH = os.environ.get('FPD_WREDUCE_PER_BATCH', '0') == '1'   # slab reduction per weight-gradient batch instead of once per gradient bucket (measured equal: 10.67 vs 10.67 ms, 22 more launches)
 # FPD_WREDUCE_MODE: where the slabs of a gradient bucket are summed on the weight-gradient lane.
 #   bucket  one reduction at the end of the bucket (round 3): the LAST bucket's reduction (130 us over 116 tensors) sits between the
 #           last weight gradient and Adam, fully exposed (profiles/r04a trace: the chain ends 435 us before Adam starts)
-#   batch   one behind every batch (= FPD_WREDUCE_PER_BATCH=1)
+#   batch   one behind every batch
 #   lag     one IN FRONT of every batch, covering the batches before it: the lane sums finished slabs while it waits for the
 #           next batch's operands anyway, and what remains behind the last weight gradient covers the last batch only
-WREDUCE_MODE = os.environ.get('FPD_WREDUCE_MODE', 'batch' if WREDUCE_PER_BATCH else 'lag')
+WREDUCE_MODE = os.environ.get('FPD_WREDUCE_MODE', 'lag')
 WGRAD_BATCH = 8     # re-swept in round 2 on one box: 1/2/4/8/12/16/24/32 -> 11.92/11.83/11.69/11.67/11.81/11.83/11.90/11.99 ms (the lane tail before Adam)
 
 
@@ -837,7 +836,7 @@ class HourglassGraph:
         fused = None        # a full-resolution train-BN term takes the ReLU mask into its statistics pass (one launch for both)
         if op.relu:
             g = Act(op.y.shape, 'g:' + op.y.name)
-            if os.environ.get('FPD_FUSE_MASK', '1') != '0':
+            if True:      # (the ReLU mask always rides the statistics pass of a full-resolution train-BN term)
                 fused = next((t for t, bn, up in op.terms if up == 1 and bn is not None and bn.mode == 'train' and t.needs_grad), None)
             if fused is None:
                 ew('relu_mask', op.y.shape, x=op.y, dy=dy, y=g)

@@ -167,7 +167,7 @@ def test_use_target_weight_flags_reach_the_fused_loss():
 
 
 def test_teacher_chunks_match_single_chunk():
-    """FPD_TEACHER_CHUNKS: the frozen teacher cut into per-chunk graphs on their own streams (bf16 fused Bottlenecks read
+    """teacher_chunks: the frozen teacher cut into per-chunk graphs on their own streams (bf16 fused Bottlenecks read
     the folded BN tables the FIRST chunk's prep pass wrote) == the one-chunk teacher map, bit for bit."""
     from fpd_amd import executor as E
     c, gold, student, teacher = _models('tiny', 'bf16')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the stem forward (7x7 stride-2 convolution of the fp32 NCHW image) at the benchmark shapes (GPU only).
-   python tools/stem_bench.py [--iters 20]      FPD_STEM_S2D=0 selects the im2col kernel (stem_fwd_mfma)"""
+   python tools/stem_bench.py [--iters 20]      (the im2col kernel stem_fwd_mfma now only serves the shapes stem_s2d declines)"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
