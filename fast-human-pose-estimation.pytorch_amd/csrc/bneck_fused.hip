@@ -277,7 +277,7 @@ __device__ __forceinline__ void bneck_eval_body(const fpd_bneck_t& a, const int 
     }
 
     // a block owns a CONTIGUOUS range of tiles (consecutive row groups of an image), so that the ring pays off
-    const int t_beg = (int)((long long)bid_in * ntiles / nblk), t_end = (int)((long long)(bid_in + 1) * ntiles / nblk);
+    const int t_beg = fpd_cut(bid_in, ntiles, nblk), t_end = fpd_cut(bid_in + 1, ntiles, nblk);
     (void)swz;
     for (int tile = t_beg; tile < t_end; ++tile) {
     {

@@ -64,6 +64,16 @@ struct LdsAttr {
     }
 };
 
+// floor(i * n / d), 0 <= i <= d: the first unit of block i's contiguous range when n units are cut into d ranges (every persistent
+// kernel starts with two of these).  As a 64-bit quotient it is ~150 dependent scalar instructions -- in front of the first load of
+// every block; the products of all shapes but absurd ones fit 32 bits (the branch is uniform).
+__device__ __forceinline__ int fpd_cut(int i, int n, int d) {
+#ifndef FPD_CUT64      // (probe build: the 64-bit quotient everywhere)
+    if (n < (1 << 20) && d < (1 << 11)) return (int)(((unsigned)i * (unsigned)n) / (unsigned)d);
+#endif
+    return (int)((long long)i * n / d);
+}
+
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 // two floats -> packed bf16x2 (lo = a), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t f2bf_pk(float a, float b) {

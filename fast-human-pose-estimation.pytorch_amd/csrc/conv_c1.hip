@@ -94,7 +94,7 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
     const int M = a.N * a.H * a.W;
     const int ntile = M >> 5;                             // (M % 32 == 0: checked by the host)
     const int nround = (ntile + C1_NW - 1) / C1_NW;
-    const int r_beg = (int)((long long)bi * nround / nblk), r_end = (int)((long long)(bi + 1) * nround / nblk);
+    const int r_beg = fpd_cut(bi, nround, nblk), r_end = fpd_cut(bi + 1, nround, nblk);
 
     float* s_scale = reinterpret_cast<float*>(smem);      // [C] prologue BN
     float* s_shift = s_scale + C;                         // [C]
@@ -592,7 +592,7 @@ struct C1Args { fpd_conv_t c[2]; int nblk[2]; };
 template <int C, int K, bool BWD, bool FOLD, bool WG, bool RES>
 __global__ __launch_bounds__(512, 2) void c1_kernel(const C1Args p) {
     const int bid = blockIdx.x, n = gridDim.x, nb = p.nblk[1];
-    const int fb0 = (int)((long long)bid * nb / n), fb1 = (int)((long long)(bid + 1) * nb / n);
+    const int fb0 = fpd_cut(bid, nb, n), fb1 = fpd_cut(bid + 1, nb, n);
     const int isb = fb1 > fb0 ? 1 : 0;
     const int u = isb ? fb0 : bid - fb0;
     c1_body<C, K, BWD, FOLD, WG, RES>(p.c[isb], u, p.nblk[isb]);
@@ -621,18 +621,15 @@ int c1_min_px() {
     if (v < 0) { const char* e = getenv("FPD_C1_MIN_PX"); v = e ? atoi(e) : 2048; }
     return v;
 }
-int c1_fuse_wgrad() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FPD_C1_WGRAD"); v = e ? atoi(e) : 1; }
-    return v;
-}
+int c1_fuse_wgrad() { return 1; }
 
 bool c1_chan(int c) { return c == 32 || c == 64 || c == 128; }
 bool c1_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool c1_domain(const fpd_conv_t& a) {
     if (a.dtype != FPD_BF16 || a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.P != a.H || a.Q != a.W) return false;
-    if (!c1_chan(a.C) || !c1_chan(a.K)) return false;
+    // (16 -> 128: the inter-stack score_ convolution and the data gradient of the score convolution, hourglass.py:136-137, one k-step)
+    if (!(c1_chan(a.C) || (a.C == 16 && a.K == 128)) || !c1_chan(a.K)) return false;
     const long long M = (long long)a.N * a.H * a.W;
     if (M % 32 != 0 || M > (1ll << 30)) return false;
     if (!c1_aligned(a.x) || !c1_aligned(a.y) || !c1_aligned(a.w) || !c1_aligned(a.residual) || !c1_aligned(a.epi_x) ||
@@ -640,7 +637,8 @@ bool c1_domain(const fpd_conv_t& a) {
     if (a.epi == FPD_EPI_BNRELU_BWD) {
         // the data gradients of the hot path: no bias, no accumulate source, no prologue BN; dW tiles for every wave
         if (a.bias != nullptr || a.residual != nullptr || a.bn.mode != FPD_BN_NONE) return false;
-        if ((a.C / 32) * (a.K / 32) != C1_NW) return false;      // 128 <-> 64 (128 x 128: the tiles of 8 waves do not fit the LDS)
+        if (a.C == 16) { if (a.fold_x != nullptr) return false; }      // (no dW tiles: its weight gradient stays a separate launch)
+        else if ((a.C / 32) * (a.K / 32) != C1_NW) return false;      // 128 <-> 64 (128 x 128: the tiles of 8 waves do not fit the LDS)
     } else {
         if (a.epi != FPD_EPI_PLAIN || a.fold_x != nullptr || a.wg_partial != nullptr) return false;
         if (a.y == a.x) return false;
@@ -648,7 +646,7 @@ bool c1_domain(const fpd_conv_t& a) {
     return true;
 }
 bool c1_wg_shape(const fpd_conv_t& a) {
-    return c1_fuse_wgrad() != 0 && c1_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && ((a.C / 32) * (a.K / 32)) % C1_NW == 0;
+    return c1_fuse_wgrad() != 0 && c1_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && (a.C / 32) * (a.K / 32) >= C1_NW && ((a.C / 32) * (a.K / 32)) % C1_NW == 0;
 }
 int c1_rounds(const fpd_conv_t& a) { return cdiv(a.N * a.H * a.W / 32, C1_NW); }
 
@@ -706,6 +704,8 @@ int c1_launch_ck(const fpd_conv_t& a, const fpd_conv_t* b, const C1Plan& pl, hip
             if (a.fold_x != nullptr || (b != nullptr && b->fold_x != nullptr))
                 return pl.wg ? c1_launch_t<C, K, true, true, true, false>(a, b, pl, st) : c1_launch_t<C, K, true, true, false, false>(a, b, pl, st);
             return pl.wg ? c1_launch_t<C, K, true, false, true, false>(a, b, pl, st) : c1_launch_t<C, K, true, false, false, false>(a, b, pl, st);
+        } else if constexpr (C == 16) {
+            return c1_launch_t<C, K, true, false, false, false>(a, b, pl, st);
         } else {
             return 1;
         }
@@ -743,6 +743,7 @@ int c1_launch(const fpd_conv_t& a, const fpd_conv_t* b, hipStream_t st) {
             return fpd_fail(-2, "conv_pair: both or neither convolution of a pair take a fused weight gradient");
     }
     switch (a.C) {
+        case 16: return c1_launch_ck<16, 128>(a, b, pl, st);
         case 32: return c1_launch_c<32>(a, b, pl, st);
         case 64: return c1_launch_c<64>(a, b, pl, st);
         default: return c1_launch_c<128>(a, b, pl, st);

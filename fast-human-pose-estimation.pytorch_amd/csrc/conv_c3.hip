@@ -70,7 +70,7 @@ __device__ __forceinline__ void c3_body(const fpd_conv_t& a, const C3Geo g, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.W, H = a.H, lgW = g.lgW, RS = g.rs, WP = W + 2;
     const int M = a.N * H * W;
-    const int s_beg = (int)((long long)bi * g.nstrip / g.nblk), s_end = (int)((long long)(bi + 1) * g.nstrip / g.nblk);
+    const int s_beg = fpd_cut(bi, g.nstrip, g.nblk), s_end = fpd_cut(bi + 1, g.nstrip, g.nblk);
     const int spi = H / RS;                               // strips per image
 
     float* s_scale = reinterpret_cast<float*>(smem);      // [C] prologue BN
@@ -433,7 +433,7 @@ struct C3Args { fpd_conv_t c[2]; C3Geo g[2]; };
 template <bool BWD, bool FOLD>
 __global__ __launch_bounds__(512, 2) void c3_kernel(const C3Args p) {
     const int bid = blockIdx.x, n = gridDim.x, nb = p.g[1].nblk;
-    const int fb0 = (int)((long long)bid * nb / n), fb1 = (int)((long long)(bid + 1) * nb / n);
+    const int fb0 = fpd_cut(bid, nb, n), fb1 = fpd_cut(bid + 1, nb, n);
     const int isb = fb1 > fb0 ? 1 : 0;
     const int u = isb ? fb0 : bid - fb0;
     c3_body<BWD, FOLD>(p.c[isb], p.g[isb], u);

@@ -142,8 +142,8 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     bf16_t* fo = (fold && n0 == 0) ? reinterpret_cast<bf16_t*>(a.fold_out) : nullptr;     // written once: by the first K slab
 
     // ---- this block's tiles: a contiguous range ----
-    const int t_beg = (int)((long long)bi * geo.ntiles / geo.nblk);
-    const int t_end = (int)((long long)(bi + 1) * geo.ntiles / geo.nblk);
+    const int t_beg = fpd_cut(bi, geo.ntiles, geo.nblk);
+    const int t_end = fpd_cut(bi + 1, geo.ntiles, geo.nblk);
 
     // ---- operand staging: vector v = tid + 512 i of the tile's hrows x W x CPR operand vectors (a thread always stages the
     //      same 8 channels: 512 % CPR == 0).  Loads are unconditional (rows outside the tensor: clamped address, cleared bit).
@@ -704,7 +704,7 @@ struct PPArgs { fpd_conv_t c[2]; PPGeo g[2]; int ks; };
 template <int R, int C, int KH, bool BWD, bool WG>
 __global__ __launch_bounds__(512, BWD ? 2 : 4) void conv_pp_kernel(const PPArgs p) {
     const int bid = blockIdx.x, n = gridDim.x, ks = p.ks, nb = p.g[1].nblk * ks;
-    const int fb0 = (int)((long long)bid * nb / n), fb1 = (int)((long long)(bid + 1) * nb / n);
+    const int fb0 = fpd_cut(bid, nb, n), fb1 = fpd_cut(bid + 1, nb, n);
     const int isb = fb1 > fb0 ? 1 : 0;                    // (the descriptor is indexed, not branched on: ONE copy of the body)
     const int u = isb ? fb0 : bid - fb0;
     const int nr = p.g[isb].nblk;

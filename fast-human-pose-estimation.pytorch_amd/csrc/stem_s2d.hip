@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stem_s2d_fwd_kernel(const fpd_stem_t a, c
 #endif
     S2_STAMP();
     // this block's contiguous tile range
-    const int t_beg = (int)((long long)blockIdx.x * ntiles / gridDim.x), t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+    const int t_beg = fpd_cut((int)blockIdx.x, ntiles, (int)gridDim.x), t_end = fpd_cut((int)blockIdx.x + 1, ntiles, (int)gridDim.x);
     if (t_beg >= t_end) return;
 
     // ---- once per block: weights -> bf16 [k][tap = kr*4 + ks][ch = (dy*3 + c)*2 + dx], zero where the slot has no tap ----
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void stem_s2d_wgrad_kernel(const fpd_stem_t a,
     const float* __restrict__ x = a.x;
     const bf16_t* __restrict__ dyp = reinterpret_cast<const bf16_t*>(a.dy);
     auto wrap = [&](unsigned v) { return min(v, v - RINGB); };
-    const int t_beg = (int)((long long)blockIdx.x * ntiles / gridDim.x), t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+    const int t_beg = fpd_cut((int)blockIdx.x, ntiles, (int)gridDim.x), t_end = fpd_cut((int)blockIdx.x + 1, ntiles, (int)gridDim.x);
 
     for (int i = tid; i < RING * QP; i += 256) *reinterpret_cast<uint2*>(sS + (unsigned)i * S2_PIXB + 24) = make_uint2(0u, 0u);
     for (int i = tid; i < 128 * 4; i += 256) *reinterpret_cast<uint4*>(sD + i * 16) = make_uint4(0, 0, 0, 0);      // columns >= K stay zero

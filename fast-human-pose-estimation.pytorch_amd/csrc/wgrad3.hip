@@ -88,7 +88,7 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3_kernel(const fpd_wgrad_t a, 
     const int cpieces = C / W3_CH;
     const int kt = piece / cpieces, ct = piece - kt * cpieces;
     const int k0 = kt * W3_CH, c0 = ct * W3_CH;
-    const int t_begin = (int)(((long long)range * mtiles) / nranges), t_end = (int)(((long long)(range + 1) * mtiles) / nranges);
+    const int t_begin = fpd_cut(range, mtiles, nranges), t_end = fpd_cut(range + 1, mtiles, nranges);
     const int ntl = t_end - t_begin;
 
 #ifdef W3_TIMING
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(W3_BLK, 2) void wgrad3s_kernel(const fpd_wgrad_t a,
     const int cpieces = C / W3_CH;
     const int kt = piece / cpieces, ct = piece - kt * cpieces;
     const int k0 = kt * W3_CH, c0 = ct * W3_CH;
-    const int t_begin = (int)(((long long)range * mtiles) / nranges), t_end = (int)(((long long)(range + 1) * mtiles) / nranges);
+    const int t_begin = fpd_cut(range, mtiles, nranges), t_end = fpd_cut(range + 1, mtiles, nranges);
     const int ntl = t_end - t_begin;
 #ifdef W3_TIMING
     if (threadIdx.x == 0) w3_ns = 0;

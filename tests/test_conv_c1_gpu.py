@@ -34,6 +34,8 @@ FWD_CASES = [
     (1, 4, 40, 128, 64, 'train', True, True, 2),          # 5 tiles: a ragged last round (3 waves of the block idle)
     (3, 4, 8, 64, 128, 'train', True, True, 1),           # 3 tiles in ONE round
     (1, 8, 52, 64, 64, 'train', False, True, 3),          # 13 tiles, 2 rounds over 3 blocks (an idle block)
+    (2, 64, 64, 16, 128, None, True, True, 4),            # score_: C = J = 16 (one k-step) + residual
+    (2, 32, 32, 16, 128, None, False, False, 3),
 ]
 
 
@@ -200,6 +202,23 @@ def test_c1_dgrad_close_to_conv_pp(case):
     for i, nm in ((1, 'sums'), (2, 'dw'), (3, 'dbias')):
         a, b = res[0][i], res[1][i]
         assert ((a - b).abs() <= 5e-5 * a.abs().max() + 1e-9).all(), (nm, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 128, 16, 4), (3, 16, 16, 128, 16, 2)])
+def test_c1_dgrad_of_the_score_convolution(case):
+    """Forward convolution 128 -> J = 16 (hourglass.py:136): its data gradient has 16 input channels (one k-step), the usual
+    BatchNorm-backward epilogue and NO fused weight gradient (no 32 x 32 tile of dW exists): the separate launch must agree."""
+    N, H, W, C, K, blocks = case
+    gen = torch.Generator().manual_seed(181 + sum(case))
+    bt = Bench(1)
+    ops, o = _dgrad_ops(bt, gen, (N, H, W, C, K, blocks, True), False, True)
+    bt.realise().run(ops, ('c1', blocks), partials=True)
+    assert bt.n_c1 == 1 and bt.n_fused == 0
+    bt.compare(o['dz'], label='score dgrad dz %s' % (case,), **TOL[1])
+    bt.compare(o['bst'], atol=TOL[1]['atol'] * N * H * W, rtol=TOL[1]['rtol'], label='score dgrad bn sums')
+    tol = dict(atol=2e-2 + 2e-5 * N * H * W, rtol=3e-2)
+    bt.compare(o['dw'], label='score wgrad dw', **tol)
+    bt.compare(o['db'], label='score wgrad dbias', **tol)
 
 
 def test_c1_dgrad_is_bit_repeatable():
