@@ -189,17 +189,23 @@ __device__ __forceinline__ double stats_sum(const fpd_stat_t* buf, int C, int s,
 // bn_request() only issues the loads of channel c, bn_resolve() does the arithmetic on what arrived.
 struct BnRaw { StatRaw s1, s2; float g, b, eps, rm, rv; int mode; };
 __device__ __forceinline__ void bn_request(const fpd_bn_t& bn, int c, int C, BnRaw& r) {
+    // Three disjoint paths, every field a path needs assigned exactly ONCE in it and nothing else touched (bn_resolve reads
+    // s1 / s2 only in TRAIN mode, rm / rv only otherwise).  The earlier form -- defaults first, loads over them -- let hipcc sink
+    // the default writes of rm / rv behind the gamma / beta loads of the TRAIN path: a write to a register with a load possibly
+    // in flight needs `s_waitcnt vmcnt(0)`, so the sixteen statistics loads were ISSUED only after gamma and beta had arrived
+    // -- one more memory round trip in front of every block of every kernel with a BatchNorm prologue or epilogue (r06, found
+    // in conv_c1's assembly: 12.7 k cycles to the first barrier of the 64x64 data gradients).
     r.mode = bn.mode; r.eps = bn.eps;
-#pragma unroll
-    for (int q = 0; q < FPD_STATS_REPLICAS; ++q) { r.s1.hi[q] = r.s1.lo[q] = r.s2.hi[q] = r.s2.lo[q] = 0; }
-    r.g = 1.f; r.b = 0.f; r.rm = 0.f; r.rv = 1.f;
-    if (bn.mode == FPD_BN_NONE) return;
-    r.g = bn.gamma[c];
-    r.b = bn.beta[c];
     if (bn.mode == FPD_BN_TRAIN) {
+        r.g = bn.gamma[c];
+        r.b = bn.beta[c];
         stat_request(bn.stats, C, 0, c, r.s1);
         stat_request(bn.stats, C, 1, c, r.s2);
+    } else if (bn.mode == FPD_BN_NONE) {
+        r.g = 1.f; r.b = 0.f; r.rm = 0.f; r.rv = 1.f;
     } else {
+        r.g = bn.gamma[c];
+        r.b = bn.beta[c];
         r.rm = bn.running_mean[c];
         r.rv = bn.running_var[c];
     }

@@ -128,7 +128,8 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
 
     // ---- prologue: the table chains (loads -> fp64 -> LDS) on different waves, requested before the long loads ----
     BnRaw braw;
-    float bias_raw = 0.f;
+    float bias_raw;                                      // (set in the r_bias branch only: a default written here is sunk by hipcc
+                                                          //  behind the other branches' loads, where it needs vmcnt(0) -- see bn_request)
     const int te = tid - 128, tb = tid - 256;
     const bool r_bn = has_bn && tid < C;
     const bool r_fold = fold && tid < C;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
         stat_request(a.fold_stats, C, 1, tid, fs2);
     }
     else if (r_epi) bn_request(a.epi_bn, te, K, braw);
-    else if (r_bias && a.bias != nullptr) bias_raw = a.bias[tb];
+    else if (r_bias) { bias_raw = 0.f; if (a.bias != nullptr) bias_raw = a.bias[tb]; }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- the tile's vectors: vector i of a lane is 16 bytes at (tile base) + (i * 64 + lane) * 16 -- whole 1 KB lines ----
@@ -621,6 +622,11 @@ int c1_min_px() {
     if (v < 0) { const char* e = getenv("FPD_C1_MIN_PX"); v = e ? atoi(e) : 2048; }
     return v;
 }
+int c1_min_px_bwd() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FPD_C1_MIN_PX_BWD"); v = e ? atoi(e) : 2048; }
+    return v;
+}
 int c1_fuse_wgrad() { return 1; }
 
 bool c1_chan(int c) { return c == 32 || c == 64 || c == 128; }
@@ -659,7 +665,7 @@ bool c1_takes(const fpd_conv_t& a, const fpd_conv_t* b) {
         if ((a.residual != nullptr) != (b->residual != nullptr)) return false;      // (the residual is a template parameter)
         px += (long long)b->N * b->H * b->W;
     }
-    return mode != 1 || px >= c1_min_px();
+    return mode != 1 || px >= (a.epi == FPD_EPI_BNRELU_BWD ? c1_min_px_bwd() : c1_min_px());
 }
 
 struct C1Plan { int na, nb, grid; bool wg; };

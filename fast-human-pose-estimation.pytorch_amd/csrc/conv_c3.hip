@@ -95,7 +95,8 @@ __device__ __forceinline__ void c3_body(const fpd_conv_t& a, const C3Geo g, cons
 
     // ---- prologue: table chains requested first, then the weights, then the first strip (conv_c1.hip) ----
     BnRaw braw;
-    float bias_raw = 0.f;
+    float bias_raw;                                      // (set in the r_bias branch only: a default written here is sunk by hipcc
+                                                          //  behind the other branches' loads, where it needs vmcnt(0) -- see bn_request)
     const int te = tid - 128, tb = tid - 256;
     const bool r_bn = has_bn && tid < C;
     const bool r_fold = fold && tid < C;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void c3_body(const fpd_conv_t& a, const C3Geo g, cons
         stat_request(a.fold_stats, C, 1, tid, fs2);
     }
     else if (r_epi) bn_request(a.epi_bn, te, K, braw);
-    else if (r_bias && a.bias != nullptr) bias_raw = a.bias[tb];
+    else if (r_bias) { bias_raw = 0.f; if (a.bias != nullptr) bias_raw = a.bias[tb]; }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- the strip's operand vectors: vector v = tid + 512 i of its (RS + 2) rows x W pixels x 8 chunks is 16 bytes at

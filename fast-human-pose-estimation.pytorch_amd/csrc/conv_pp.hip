@@ -280,7 +280,8 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
     //      only then is anything waited for -- the chains run concurrently with each other and under the long loads instead
     //      of one after the other in waves 0-1 (measured: 6.7 k -> cycles from entry to the first barrier).
     BnRaw braw;
-    float bias_raw = 0.f;
+    float bias_raw;                                      // (set in the r_bias branch only: a default written here is sunk by hipcc
+                                                          //  behind the other branches' loads, where it needs vmcnt(0) -- see bn_request)
     const int te = tid - 128, tb = tid - 256;
     const bool r_bn = a.bn.mode != FPD_BN_NONE && tid < C;
     const bool r_epi = a.epi == FPD_EPI_BNRELU_BWD && te >= 0 && te < KP;
@@ -294,7 +295,7 @@ __device__ __forceinline__ void conv_pp_body(const fpd_conv_t& a, const PPGeo ge
         stat_request(a.fold_stats, C, 1, tid, fs2);
     }
     else if (r_epi && n0 + te < K) bn_request(a.epi_bn, n0 + te, K, braw);
-    else if (r_bias && a.bias != nullptr && n0 + tb < K) bias_raw = a.bias[n0 + tb];
+    else if (r_bias) { bias_raw = 0.f; if (a.bias != nullptr && n0 + tb < K) bias_raw = a.bias[n0 + tb]; }
     __builtin_amdgcn_sched_barrier(0);
     if (t_beg < t_end) halo_load(t_beg);
     PP_STAMP();

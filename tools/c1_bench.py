@@ -22,6 +22,17 @@ SHAPES = [
     ('bwd+wg of 64>128 @32', 32, 32, 32, 64, 128, 'bwd'),
     ('bwd+wg+fold of 128>64 @32', 32, 32, 32, 128, 64, 'bwd+fold'),
     ('fwd 32>64+res @128', 32, 128, 128, 32, 64, 'fwd+res'),
+    ('fwd 128>64 @8', 32, 8, 8, 128, 64, 'fwd'),
+    ('bwd+wg+fold of 128>64 @8', 32, 8, 8, 128, 64, 'bwd+fold'),
+    ('fwd 128>64 @16', 32, 16, 16, 128, 64, 'fwd'),
+    ('bwd+wg of 64>128 @16', 32, 16, 16, 64, 128, 'bwd'),
+    ('bwd+wg+fold of 128>64 @16', 32, 16, 16, 128, 64, 'bwd+fold'),
+    ('bwd+wg of 64>128 @8', 32, 8, 8, 64, 128, 'bwd'),
+    ('fwd 64>128+res @8', 32, 8, 8, 64, 128, 'fwd+res'),
+    ('fwd 128>64 @4', 32, 4, 4, 128, 64, 'fwd'),
+    ('fwd 64>128+res @4', 32, 4, 4, 64, 128, 'fwd+res'),
+    ('bwd+wg of 64>128 @4', 32, 4, 4, 64, 128, 'bwd'),
+    ('bwd+wg+fold of 128>64 @4', 32, 4, 4, 128, 64, 'bwd+fold'),
     ('3x3 fwd 64>64 @64', 32, 64, 64, 64, 64, 'fwd', 3),
     ('3x3 bwd+fold 64>64 @64', 32, 64, 64, 64, 64, 'bwd+fold', 3),
     ('3x3 fwd 64>64 @32', 32, 32, 32, 64, 64, 'fwd', 3),
