@@ -615,11 +615,15 @@ int c1_blocks() {
     if (g_c1_blocks < 0) { const char* e = getenv("FPD_C1_BLOCKS"); g_c1_blocks = e ? atoi(e) : 192; }
     return g_c1_blocks < 1 ? 1 : g_c1_blocks;
 }
+// Smallest launch (pixels) the kernel takes in mode 1, forward launches and data gradients apart.  Kernels alone on the small maps
+// (profiles/r06_c1_small_maps.txt): the forward 128 -> 64 wins at every size (7.5 vs 8.9-9.2 us down to 4x4 = 512 pixels), the data
+// gradients with their fused weight gradient lose 1 us to conv_tile's plain data gradient below 32x32 -- but take the weight gradient
+// off the lane.  Inside the step (one box, three interleaved runs each): forward / backward 2048 / 2048 -> 8.763, 8.823, 8.764 ms;
+// 512 / 2048 -> 8.762, 8.760, 8.747; 512 / 8192 -> 8.755, 8.750, 8.768; 512 / 16384 -> 8.796, 8.763, 8.807; the earlier sweep of
+// both together: 32768 / 8192 / 2048 / 512 -> 9.669 / 9.60 / 9.574 / 9.581.
 int c1_min_px() {
     static int v = -1;
-    // (r06 what-if on one box: 32768 / 8192 / 2048 / 512 pixels -> 9.669 / 9.60 / 9.574 / 9.581 ms per step: from the 8x8 level up the
-    //  kernel also beats the halo-tile kernel and takes the 1x1 weight gradients of those levels off the lane)
-    if (v < 0) { const char* e = getenv("FPD_C1_MIN_PX"); v = e ? atoi(e) : 2048; }
+    if (v < 0) { const char* e = getenv("FPD_C1_MIN_PX"); v = e ? atoi(e) : 512; }
     return v;
 }
 int c1_min_px_bwd() {
