@@ -59,7 +59,8 @@ struct C1Geo {
     static constexpr int KT = K / 32, KS = C / 16;       // 32-channel output tiles, 16-channel reduction steps
     static constexpr int PXA = C * 2 + 16, PXO = K * 2 + 16;     // pixel pitch of the operand / output tile (bytes)
     static constexpr int TILE_A = 32 * PXA, TILE_O = 32 * PXO;
-    static constexpr int WAVE_LDS = BWD ? TILE_A + TILE_O : (TILE_A > TILE_O ? TILE_A : TILE_O);
+    // (only the fused weight gradient reads the operand tile after the products: without it the output tile takes its place)
+    static constexpr int WAVE_LDS = WG ? TILE_A + TILE_O : (TILE_A > TILE_O ? TILE_A : TILE_O);
     static constexpr int FLUSH = C1_NW * 64 * 16 * 4 + C1_NW * K * 4 + 8 * 2 * K * 8;      // statistics records + common shifts + partial sums
     static constexpr int REGION = C1_NW * WAVE_LDS > FLUSH ? C1_NW * WAVE_LDS : FLUSH;
     static constexpr int TABLES = (2 * C + (BWD ? 3 * C + 4 * K : 0) + K) * 4;
@@ -104,7 +105,7 @@ __device__ __forceinline__ void c1_body(const fpd_conv_t& a, const int bi, const
     unsigned char* sW = reinterpret_cast<unsigned char*>(s_bias + K);     // [K][C] bf16, 16-byte chunk c of row n at c ^ sw(n)
     unsigned char* sT = sW + K * C * 2;                   // the waves' tiles
     unsigned char* tA = sT + wave * G::WAVE_LDS;          // operand tile [32 px][PXA]
-    unsigned char* tO = BWD ? tA + G::TILE_A : tA;        // output tile [32 px][PXO] (forward: the operand tile is dead by then)
+    unsigned char* tO = WG ? tA + G::TILE_A : tA;         // output tile [32 px][PXO] (no fused weight gradient: the operand tile is dead by then)
 
     const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
     const bf16_t* __restrict__ w = reinterpret_cast<const bf16_t*>(a.w);
@@ -648,7 +649,9 @@ bool c1_domain(const fpd_conv_t& a) {
         // the data gradients of the hot path: no bias, no accumulate source, no prologue BN; dW tiles for every wave
         if (a.bias != nullptr || a.residual != nullptr || a.bn.mode != FPD_BN_NONE) return false;
         if (a.C == 16) { if (a.fold_x != nullptr) return false; }      // (no dW tiles: its weight gradient stays a separate launch)
-        else if ((a.C / 32) * (a.K / 32) != C1_NW) return false;      // 128 <-> 64 (128 x 128: the tiles of 8 waves do not fit the LDS)
+        // 128 <-> 64 with the fused weight gradient; 128 x 128 (the dy + a(u) tiles of 8 waves do not fit the LDS) as a plain data
+        // gradient, its weight gradient a launch of its own on the lane
+        else if ((a.C / 32) * (a.K / 32) != C1_NW && !(a.C == 128 && a.K == 128 && a.fold_x == nullptr)) return false;
     } else {
         if (a.epi != FPD_EPI_PLAIN || a.fold_x != nullptr || a.wg_partial != nullptr) return false;
         if (a.y == a.x) return false;
@@ -656,7 +659,7 @@ bool c1_domain(const fpd_conv_t& a) {
     return true;
 }
 bool c1_wg_shape(const fpd_conv_t& a) {
-    return c1_fuse_wgrad() != 0 && c1_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && (a.C / 32) * (a.K / 32) >= C1_NW && ((a.C / 32) * (a.K / 32)) % C1_NW == 0;
+    return c1_fuse_wgrad() != 0 && c1_domain(a) && a.epi == FPD_EPI_BNRELU_BWD && (a.C / 32) * (a.K / 32) == C1_NW;
 }
 int c1_rounds(const fpd_conv_t& a) { return cdiv(a.N * a.H * a.W / 32, C1_NW); }
 
@@ -714,7 +717,7 @@ int c1_launch_ck(const fpd_conv_t& a, const fpd_conv_t* b, const C1Plan& pl, hip
             if (a.fold_x != nullptr || (b != nullptr && b->fold_x != nullptr))
                 return pl.wg ? c1_launch_t<C, K, true, true, true, false>(a, b, pl, st) : c1_launch_t<C, K, true, true, false, false>(a, b, pl, st);
             return pl.wg ? c1_launch_t<C, K, true, false, true, false>(a, b, pl, st) : c1_launch_t<C, K, true, false, false, false>(a, b, pl, st);
-        } else if constexpr (C == 16) {
+        } else if constexpr (C == 16 || (C == 128 && K == 128)) {
             return c1_launch_t<C, K, true, false, false, false>(a, b, pl, st);
         } else {
             return 1;

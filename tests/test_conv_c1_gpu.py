@@ -204,10 +204,11 @@ def test_c1_dgrad_close_to_conv_pp(case):
         assert ((a - b).abs() <= 5e-5 * a.abs().max() + 1e-9).all(), (nm, float((a - b).abs().max()), float(a.abs().max()))
 
 
-@pytest.mark.parametrize('case', [(2, 64, 64, 128, 16, 4), (3, 16, 16, 128, 16, 2)])
+@pytest.mark.parametrize('case', [(2, 64, 64, 128, 16, 4), (3, 16, 16, 128, 16, 2), (2, 32, 32, 128, 128, 3), (1, 64, 64, 128, 128, 5)])
 def test_c1_dgrad_of_the_score_convolution(case):
     """Forward convolution 128 -> J = 16 (hourglass.py:136): its data gradient has 16 input channels (one k-step), the usual
-    BatchNorm-backward epilogue and NO fused weight gradient (no 32 x 32 tile of dW exists): the separate launch must agree."""
+    BatchNorm-backward epilogue and NO fused weight gradient (no 32 x 32 tile of dW exists): the separate launch must agree.
+    The same for 128 -> 128 (fc_, hourglass.py:137): sixteen tiles of dW do not fit beside the tiles of eight waves."""
     N, H, W, C, K, blocks = case
     gen = torch.Generator().manual_seed(181 + sum(case))
     bt = Bench(1)
