@@ -180,7 +180,7 @@ def time_plan_op(R, plan, k, launches):
     return l.fpd_event_elapsed_ms(e0, e1) / launches * 1e3
 
 
-def conv_classes(step, R, peak_tflops, launches=12, top=6):
+def conv_classes(step, R, peak_tflops, launches=12, top=12):
     """Every (role, kind, shape) class of convolution launch of the step -- student forward / data gradient / weight
     gradient, teacher forward -- with its launch count, one recorded representative timed live (the op of the step's own
     plan, same arguments, grid and slabs), and its roofline: algorithmic FLOPs and bytes (operand in + result out, bf16),
