@@ -39,6 +39,12 @@ __device__ __forceinline__ void head_tables(const fpd_head_t& a, float* out, int
     for (int c = tid; c < 32; c += nthreads) out[2 * C + c] = (c < a.J && a.b_score) ? a.b_score[c] : 0.f;
 }
 
+#ifdef FPD_HEAD_TIMING      // probe build only (tools/probes): cycle stamps of block 0 at the phase boundaries of its LAST tile
+#define HSTAMP() do { if (tid == 0 && blockIdx.x == 0 && hn < 24) hst[hn++] = clock64(); } while (0)
+#else
+#define HSTAMP() do { } while (0)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, const int ntiles) {
     constexpr int LDX = 64 + 8;                 // [.][64]-chunk rows (bf16 elements)
@@ -51,6 +57,9 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
     constexpr int WTILE = C * LDX;              // one weight buffer (elements)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FPD_HEAD_TIMING
+    long long hst[24]; int hn = 0; int ntl = 0;
+#endif
     const int q = wave & 3, hC = wave >> 2;
     const int koff = 8 * (lane >> 5);
     const int M = a.N * a.H * a.W, J = a.J;
@@ -138,6 +147,10 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int t = ((ntiles & 7) == 0) ? (tile & 7) * (ntiles >> 3) + (tile >> 3) : tile;
         m0 = t * 128;
+#ifdef FPD_HEAD_TIMING
+        hn = 0; ++ntl;
+#endif
+        HSTAMP();
         static_for<NCH>([&](auto kcc) { a_load(kcc); });
         t_load(std::integral_constant<int, 0>{});
         t_load(std::integral_constant<int, 1>{});
@@ -146,6 +159,7 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
         t_store(std::integral_constant<int, 0>{});
         t_load(std::integral_constant<int, 2>{});
         __syncthreads();
+        HSTAMP();
 
         const int ml = q * 32 + (lane & 31);
         f32x16 acc[4];
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
                     }
                 }
                 __syncthreads();
+                HSTAMP();
             }
             if constexpr (s == NCH - 1) {
                 // ---- a = relu(bn(fc + b)) -> bf16 image (overwrites the staging buffers: every wave passed the barrier)
@@ -243,8 +258,10 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
                     }
                 }
                 __syncthreads();                 // score image visible; the score-weight tile may be overwritten
+                HSTAMP();
             }
         });
+        HSTAMP();
 
         if (has_next) {
             // ---- next = fc_(a) + score_(score) + biases + x ----
@@ -288,7 +305,16 @@ __global__ __launch_bounds__(512, 1) void head_eval_kernel(const fpd_head_t a, c
                 });
             });
         }
+        HSTAMP();
     }
+#ifdef FPD_HEAD_TIMING
+    if (tid == 0 && blockIdx.x == 0) {
+        // top | first chunk staged | steps 0..3 (fc) | a image + score | steps 4..7 (fc_) | score_ MFMAs | epilogue
+        printf("head tiles %d stamps %d:", ntl, hn);
+        for (int i = 1; i < hn; ++i) printf(" %lld", hst[i] - hst[i - 1]);
+        printf(" | total %lld\n", hst[hn - 1] - hst[0]);
+    }
+#endif
 }
 
 template <int C>
